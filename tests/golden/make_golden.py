@@ -1,0 +1,154 @@
+"""Generate golden fixtures by running the REAL reference (/root/reference) on CPU.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference cannot travel to the GPU box, so its outputs are committed here as small
+fixtures.  Inputs are NOT stored: they are re-derived from (seed, shape, kind) with the
+deterministic CPU generator in ``tests/inputs.py``; each fixture carries an input checksum
+so RNG drift is detected rather than silently mis-compared.
+
+Each fixture holds, per case: the config, the reference's compacted K/V bit patterns, the
+indices the reference picked (recovered by matching gathered K rows to source rows), and
+for AdaKV/HeadKV the var-len metadata.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, "/root/reference")
+
+from inputs import make_qkv, bits, checksum  # noqa: E402
+from pyramidkv import pyramidkv_utils as ref  # noqa: E402  (the real reference)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def recover_indices(K, Kc_past):
+    """K [B,H,L,D] source rows, Kc_past [B,H,k,D] gathered rows -> int32 [B,H,k]."""
+    B, H, L, D = K.shape
+    k = Kc_past.shape[2]
+    out = np.zeros((B, H, k), dtype=np.int32)
+    Kb, Cb = bits(K), bits(Kc_past)
+    for b in range(B):
+        for h in range(H):
+            table = {}
+            for s in range(L):
+                table.setdefault(Kb[b, h, s].tobytes(), s)
+            for j in range(k):
+                out[b, h, j] = table[Cb[b, h, j].tobytes()]
+    return out
+
+
+CASES = []
+
+
+def case(**kw):
+    CASES.append(kw)
+
+
+# policy, dtype, kind(gauss|lattice), B,H,S, w, cap, ks, pool, extra
+for dt in ("bf16", "fp16"):
+    for pool, ks in (("maxpool", 7), ("avgpool", 5)):
+        case(policy="snapkv", dtype=dt, kind="gauss", B=1, H=4, S=512, w=8, cap=64, ks=ks, pool=pool, seed=11)
+        case(policy="snapkv", dtype=dt, kind="lattice", B=2, H=2, S=384, w=32, cap=96, ks=ks, pool=pool, seed=12)
+case(policy="snapkv", dtype="fp32", kind="gauss", B=1, H=2, S=300, w=8, cap=40, ks=7, pool="maxpool", seed=13)
+case(policy="snapkv", dtype="bf16", kind="gauss", B=1, H=2, S=48, w=8, cap=64, ks=7, pool="maxpool", seed=14)  # passthrough
+for layer in (0, 15, 31):
+    case(policy="pyramidkv", dtype="bf16", kind="gauss", B=1, H=4, S=1024, w=8, cap=64, ks=7, pool="maxpool",
+         seed=21, layers=32, layer=layer)
+case(policy="pyramidkv", dtype="fp16", kind="gauss", B=1, H=2, S=100, w=8, cap=64, ks=5, pool="avgpool",
+     seed=22, layers=32, layer=3)      # 'snap' branch: cap <= S < 2(cap-w)
+case(policy="pyramidkv", dtype="bf16", kind="gauss", B=1, H=2, S=115, w=8, cap=64, ks=7, pool="maxpool",
+     seed=23, layers=32, layer=31)     # clamp branch: max_num >= S-w
+case(policy="pyramidkv", dtype="bf16", kind="gauss", B=1, H=2, S=115, w=8, cap=64, ks=7, pool="maxpool",
+     seed=24, layers=32, layer=0)      # clamp branch, k = S-w = L (keep everything)
+case(policy="h2o", dtype="bf16", kind="gauss", B=1, H=2, S=256, w=8, cap=48, ks=0, pool="none", seed=31)
+case(policy="h2o", dtype="fp16", kind="lattice", B=1, H=2, S=192, w=16, cap=40, ks=0, pool="none", seed=32)
+case(policy="streamingllm", dtype="bf16", kind="gauss", B=2, H=2, S=256, w=60, cap=64, ks=0, pool="none", seed=41)
+case(policy="adakv", dtype="bf16", kind="gauss", B=1, H=4, S=512, w=8, cap=64, ks=7, pool="maxpool", seed=51,
+     floor=0.2, normalize=True)
+case(policy="adakv", dtype="fp16", kind="gauss", B=1, H=4, S=384, w=32, cap=96, ks=5, pool="avgpool", seed=52,
+     floor=0.5, normalize=False)
+case(policy="adakv", dtype="bf16", kind="gauss", B=1, H=2, S=40, w=8, cap=64, ks=7, pool="maxpool", seed=53,
+     floor=0.2, normalize=True)        # base_capacity > L: not compressed
+case(policy="headkv", dtype="bf16", kind="gauss", B=1, H=4, S=512, w=8, cap=64, ks=7, pool="maxpool", seed=61,
+     head_capacity=[[10, 70, 56, 33]], layer=0)
+
+
+def run_case(c):
+    q, k, v = make_qkv(c["B"], c["H"], c["S"], 128, c["dtype"], c["kind"], c["seed"])
+    w, cap = c["w"], c["cap"]
+    pol = c["policy"]
+    meta = {}
+    if pol == "snapkv":
+        cl = ref.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
+        kc, vc = quiet(cl.update_kv, k, q, v, None, 1)
+    elif pol == "pyramidkv":
+        cl = ref.PyramidKVCluster(num_hidden_layers=c["layers"], layer_idx=c["layer"], window_size=w,
+                                  max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
+        kc, vc = quiet(cl.update_kv, k, q, v, None, 1)
+    elif pol == "h2o":
+        cl = ref.H2OKVCluster(window_size=w, max_capacity_prompt=cap)
+        kc, vc = quiet(cl.update_kv, k, q, v, None, 1)
+    elif pol == "streamingllm":
+        cl = ref.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap)
+        kc, vc = quiet(cl.update_kv, k, q, v, None, 1)
+    elif pol in ("adakv", "headkv"):
+        if pol == "adakv":
+            cl = ref.AdaKVCluster(window_size=w, kernel_size=c["ks"], pooling=c["pool"], max_capacity_prompt=cap,
+                                  floor=c["floor"], normalize=c["normalize"], layer_idx=0, num_hidden_layers=32)
+        else:
+            cl = ref.HeadKVCluster(window_size=w, kernel_size=c["ks"], pooling=c["pool"], max_capacity_prompt=cap,
+                                   layer_idx=c["layer"], num_hidden_layers=32, head_capacity=c["head_capacity"])
+        kc, vc = quiet(cl.update_kv, k, q, v)
+        meta = dict(head_lens=cl.head_lens.numpy(), cu_klen=cl.cu_klen.numpy(), cu_qlen=cl.cu_qlen.numpy(),
+                    cu_offset=cl.cu_offset.numpy(), cu_head_offset=cl.cu_head_offset.numpy(),
+                    max_seqlen_k=np.int64(cl.max_seqlen_k), klen_sum=np.int64(cl.klen_sum))
+    else:
+        raise ValueError(pol)
+    out = dict(kc=bits(kc), vc=bits(vc), in_checksum=np.int64(checksum(q, k, v)), **meta)
+    passthrough = kc is k
+    out["passthrough"] = np.bool_(passthrough)
+    if pol in ("adakv", "headkv"):
+        if kc.shape[0] != c["H"] * c["S"]:
+            hl = meta["head_lens"]
+            idx, off = [], 0
+            for h in range(c["H"]):
+                n = int(hl[h]) - w
+                rows = kc[off:off + n][None, None]
+                idx.append(recover_indices(k[:, h:h + 1, :-w], rows)[0, 0])
+                off += int(hl[h])
+            out["idx_flat"] = np.concatenate(idx).astype(np.int32)
+    elif not passthrough:
+        out["idx"] = recover_indices(k[:, :, :-w], kc[:, :, :-w])
+    return out
+
+
+def main():
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    index = []
+    for i, c in enumerate(CASES):
+        name = f"{i:02d}_{c['policy']}_{c['dtype']}_{c['kind']}_S{c['S']}"
+        out = run_case(c)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        index.append(dict(name=name, **c))
+        print(name, {k: getattr(v, 'shape', v) for k, v in out.items() if k not in ('kc', 'vc')})
+    with open(os.path.join(HERE, "index.json"), "w") as f:
+        json.dump(dict(torch=torch.__version__, reference="Zefan-Cai/PyramidKV@2024-12-20",
+                       cases=index), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

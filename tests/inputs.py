@@ -1,0 +1,68 @@
+"""Deterministic synthetic inputs shared by tests, golden generation, smoke and bench.
+
+All generation happens on the CPU generator (bit-reproducible across machines with the same
+torch build); tensors are moved to the device afterwards.
+"""
+import numpy as np
+import torch
+
+DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+
+
+def make_qkv(B, H, S, D, dtype, kind, seed, device="cpu"):
+    """kind:
+      gauss    N(0,1) fp32 -> cast (SURVEY section 8d 'tier B')
+      lattice  values in {-4..4}/4: every q.k dot product is exact in fp32 in any order ('tier A')
+      planted  gauss background + a few hundred 'heavy hitter' keys whose logits are
+               well separated, so selection is robust to 1-ulp score noise
+    """
+    g = torch.Generator().manual_seed(seed)
+    dt = DTYPES[dtype] if isinstance(dtype, str) else dtype
+    if kind == "gauss":
+        q, k, v = (torch.randn(B, H, S, D, generator=g) for _ in range(3))
+    elif kind == "lattice":
+        q, k, v = (torch.randint(-4, 5, (B, H, S, D), generator=g).float() / 4 for _ in range(3))
+    elif kind == "planted":
+        q = torch.randn(B, H, S, D, generator=g) * 0.25
+        k = torch.randn(B, H, S, D, generator=g) * 0.25
+        v = torch.randn(B, H, S, D, generator=g)
+        n_hit = max(8, min(512, S // 16))
+        for b in range(B):
+            for h in range(H):
+                pos = torch.randperm(S - 64, generator=g)[:n_hit] if S > 128 else torch.arange(0)
+                # direction shared by the window queries; hitters align with it at distinct strengths
+                u = torch.randn(D, generator=g)
+                u = u / u.norm()
+                q[b, h, -64:] += 6.0 * u
+                strength = torch.linspace(2.0, 9.0, len(pos))
+                k[b, h, pos] += strength[:, None] * u
+    else:
+        raise ValueError(kind)
+    return q.to(dt).to(device), k.to(dt).to(device), v.to(dt).to(device)
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    """Bit pattern of a tensor as a numpy integer array (bf16/fp16 -> uint16, fp32 -> uint32)."""
+    t = t.detach().cpu().contiguous()
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.view(torch.int16).numpy().view(np.uint16)
+    if t.dtype == torch.float32:
+        return t.view(torch.int32).numpy().view(np.uint32)
+    return t.numpy()
+
+
+def from_bits(a: np.ndarray, dtype) -> torch.Tensor:
+    dt = DTYPES[dtype] if isinstance(dtype, str) else dtype
+    if dt in (torch.bfloat16, torch.float16):
+        return torch.from_numpy(a.view(np.int16).copy()).view(dt)
+    return torch.from_numpy(a.view(np.int32).copy()).view(dt)
+
+
+def checksum(*tensors) -> int:
+    """Order-sensitive 63-bit checksum of bit patterns."""
+    acc = 0
+    for t in tensors:
+        a = bits(t).astype(np.uint64).ravel()
+        wts = (np.arange(a.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+        acc = (acc * 1000003 + int((a * wts).sum() % np.uint64(2**61 - 1))) % (2**63 - 1)
+    return acc
