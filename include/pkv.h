@@ -1,0 +1,159 @@
+/* pkv.h — C ABI of libpkv: the MI355X (gfx950) prefill-time KV-cache eviction path.
+ *
+ * This is the drop-in boundary for the reference's
+ *     pyramidkv/pyramidkv_utils.py  *KVCluster.update_kv        (Zefan-Cai/PyramidKV @ 2024-12-20)
+ * The reference has no FFI for this path (it is eager PyTorch); each entry point below names the
+ * reference lines it replaces.  Plain pointers and sizes only: no torch types, no pybind.
+ * The only native symbol the reference does export is the decode-time flat-cache append
+ *     csrc/csrc/cuda_api.cu:55-91  tiny_api_cuda.update_flatten_view
+ * which pkv_update_flatten_view() replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers on the device that is current when the call is made;
+ *   - every launch goes to `stream` (a hipStream_t passed as void*); no call synchronises the
+ *     device or allocates user-visible memory; workspaces are caller-provided;
+ *   - tensors are [B,H,S,D] with ELEMENT strides for b,h,s and D contiguous (stride 1);
+ *     base pointers and strides must keep every row 16-byte aligned;
+ *   - return value 0 = success, negative = pkv_status; pkv_strerror() names it.  Nothing aborts.
+ */
+#ifndef PKV_H
+#define PKV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PKV_VERSION 100 /* 0.1.0 */
+
+typedef void* pkv_stream_t; /* hipStream_t */
+
+enum pkv_status {
+  PKV_OK = 0,
+  PKV_ERR_DTYPE = -1,       /* dtype not bf16/fp16 */
+  PKV_ERR_SHAPE = -2,       /* D != 128, window/topk out of range, k > L ... */
+  PKV_ERR_ALIGN = -3,       /* pointer or stride breaks 16-byte row alignment */
+  PKV_ERR_WORKSPACE = -4,   /* workspace too small */
+  PKV_ERR_UNSUPPORTED = -5, /* valid request outside the limits of this build */
+  PKV_ERR_HIP = -6,         /* a HIP runtime call failed; see pkv_last_hip_error() */
+  PKV_ERR_NULL = -7
+};
+
+enum pkv_dtype { PKV_BF16 = 0, PKV_F16 = 1 };
+enum pkv_pool { PKV_POOL_NONE = 0, PKV_POOL_AVG = 1, PKV_POOL_MAX = 2 };
+enum pkv_reduce { PKV_REDUCE_SUM = 0, PKV_REDUCE_MEAN = 1 };
+/* how A/sqrt(D) is evaluated (pyramidkv_utils.py:317): DIV = fp32 division (ATen CPU),
+ * RCP = multiply by fp32 reciprocal (ATen GPU kernels for a host-scalar divisor). */
+enum pkv_scale { PKV_SCALE_DIV = 0, PKV_SCALE_RCP = 1 };
+
+typedef struct pkv_desc {
+  int32_t dtype;        /* pkv_dtype of q,k,v and of every score buffer */
+  int32_t B, H, S, D;   /* H = number of query heads; D must be 128 */
+  int32_t kv_group;     /* 1: k,v have H heads (post-repeat_kv, the reference contract).
+                           g>1: k,v have H/g heads (un-expanded GQA); head h reads kv head h/g */
+  int64_t q_stride[3];  /* element strides of q for b,h,s */
+  int64_t k_stride[3];
+  int64_t v_stride[3];
+  int32_t window;       /* w = window_size, 1..64 */
+  int32_t pool_kind;    /* pkv_pool */
+  int32_t pool_kernel;  /* odd, <= 17; padding = kernel/2, stride 1 (pyramidkv_utils.py:328-331) */
+  int32_t reduce;       /* pkv_reduce: SUM for SnapKV/PyramidKV (:327), MEAN for AdaKV/HeadKV (:661) */
+  int32_t scale_mode;   /* pkv_scale */
+  int32_t topk;         /* k = past tokens kept per head, 1..S-window (host-resolved per layer) */
+} pkv_desc;
+
+int pkv_version(void);
+const char* pkv_strerror(int status);
+int pkv_last_hip_error(void); /* hipError_t of the last PKV_ERR_HIP on this thread */
+
+/* Bytes of scratch pkv_score_window / pkv_score_h2o / pkv_compress need for `d` (256-B aligned). */
+size_t pkv_workspace_bytes(const pkv_desc* d);
+
+/* Observation-window score (pyramidkv_utils.py:317-333, AdaKV :649-672):
+ *   logits = (Q[-w:] K^T)/sqrt(D) -> causal corner mask -> fp32 softmax over all S keys -> round
+ *   -> sum/mean of the w rows over columns [0,S-w) -> round -> avg/max pool.
+ * scores_out: [B*H rows][scores_stride] elements of d->dtype, columns [0, S-w) written. */
+int pkv_score_window(const pkv_desc* d, const void* q, const void* k, void* scores_out,
+                     int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream);
+
+/* H2O score (pyramidkv_utils.py:544-554,561): all S query rows, SxS never materialised.
+ * Same output layout as pkv_score_window; no pooling. */
+int pkv_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores_out,
+                  int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream);
+
+/* Top-k token selection (pyramidkv_utils.py:334, :238, :270, :562): for each of `rows` score rows
+ * of length L pick the k largest, emitted in (value desc, index asc) order as int32.
+ * scores: [rows][scores_stride] of dtype; idx_out: [rows][idx_stride] int32.
+ * k_per_row (device int32[rows], may be NULL) overrides k per row (k = upper bound then). */
+int pkv_topk(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores,
+             int64_t scores_stride, const int32_t* k_per_row, int32_t* idx_out, int64_t idx_stride,
+             pkv_stream_t stream);
+
+/* Gather-compaction (pyramidkv_utils.py:335,341-346): K_out/V_out[b,h] = rows idx[b,h,0..k) of
+ * K/V[b,h,:S-w] followed by the w window rows S-w..S-1.  Outputs are contiguous [B,H,k+w,D].
+ * idx: int32 [B*H][idx_stride].  d->topk = k.  Uses d->k_stride/v_stride/kv_group. */
+int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx,
+                       int64_t idx_stride, void* k_out, void* v_out, pkv_stream_t stream);
+
+/* StreamingLLM (pyramidkv_utils.py:607-620): idx = 0..k-1 for every head; no scoring. */
+int pkv_gather_streaming(const pkv_desc* d, const void* k, const void* v, void* k_out, void* v_out,
+                         pkv_stream_t stream);
+
+/* Fused update_kv for SnapKV / PyramidKV (pyramidkv_utils.py:306-347, :197-283; k resolved by the
+ * host per layer): score -> top-k -> gather on `stream`.  idx_out (int32 [B*H][d->topk]) may be NULL
+ * (then it lives in ws). */
+int pkv_compress(const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
+                 void* v_out, int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream);
+
+/* Fused update_kv for H2O (pyramidkv_utils.py:533-575). */
+int pkv_compress_h2o(const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
+                     void* v_out, int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream);
+
+/* ---- Ada-SnapKV / HeadKV (pyramidkv_utils.py:674-757, :808-878): flat var-len output ---- */
+
+/* Per-row full descending sort (:706 attn_score.sort(descending=True)), ties index-ascending.
+ * sorted_idx: int32 [rows][L]; sorted_val (may be NULL): dtype [rows][L].  L <= 32768. */
+int pkv_sort_rows(int32_t dtype, int32_t rows, int32_t L, const void* scores, int64_t scores_stride,
+                  int32_t* sorted_idx, void* sorted_val, pkv_stream_t stream);
+
+/* Head budgets (:709-719): optional normalisation, global top-(H*base) over the flattened sorted
+ * scores, per-head counts, cap_h = round(count*(1-floor) + int(base*floor)).
+ * sorted_val: dtype [H][L] (from pkv_sort_rows).  Writes int32 head_capacity[H] (device).
+ * ws: >= 1024 + 2*H*256*4 bytes.  H <= 256.  B must be 1 (:724). */
+int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, int32_t base_capacity,
+                   double floor_ratio, int32_t normalize, int32_t* head_capacity, void* ws,
+                   size_t ws_bytes, pkv_stream_t stream);
+
+/* Var-len metadata (:682-698) from head_capacity: head_lens[H] = cap_h + w, cu_klen[H+1]
+ * (exclusive prefix + total).  All device int32. */
+int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, int32_t* head_lens,
+                     int32_t* cu_klen, pkv_stream_t stream);
+
+/* Flat gather (:733-757): for head h rows sorted_idx[h][0..cap_h) then the window tail, written at
+ * row cu_klen[h] of the flat [sum_h(cap_h+w), D] outputs.  B must be 1.  d->topk, if > 0, is an upper
+ * bound on max_h cap_h (sizes the launch); 0 = unknown (S-w). */
+int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32_t* sorted_idx,
+                    int64_t idx_stride, const int32_t* head_capacity, const int32_t* cu_klen,
+                    void* k_out, void* v_out, pkv_stream_t stream);
+
+/* Decode-time flat-cache append (csrc/csrc/cuda_api.cu:11-85 update_flatten_view): out has
+ * origin_rows + H rows; head h: copy head_lens[h] rows from cache row cu_klen[h] to out row
+ * cu_klen[h]+h, then state[h] at out row cu_klen[h+1]+h.  head_dim elements of dtype per row. */
+int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const void* cache,
+                            const void* state, const int32_t* head_lens, const int32_t* cu_klen,
+                            void* out, pkv_stream_t stream);
+
+/* ---- per-kernel device timing (hipEvent pairs on `stream`), used by bench.py ---- */
+enum pkv_kernel_id {
+  PKV_K_LOGITS = 0, PKV_K_FINALIZE = 1, PKV_K_TOPK = 2, PKV_K_GATHER = 3, PKV_K_H2O_STATS = 4,
+  PKV_K_H2O_COLSUM = 5, PKV_K_SORT = 6, PKV_K_BUDGET = 7, PKV_K_COUNT = 8
+};
+int pkv_prof_enable(int on);                                   /* returns previous state */
+int pkv_prof_read(double* ms_sum, int64_t* launches, int reset); /* arrays of PKV_K_COUNT; syncs events */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PKV_H */

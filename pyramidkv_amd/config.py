@@ -1,0 +1,12 @@
+"""Process-wide knobs of pyramidkv_amd (read at call time)."""
+import os
+
+# How A / sqrt(head_dim) (reference pyramidkv_utils.py:317) is evaluated:
+#   "div": fp32 division, what ATen does on CPU (the oracle's arithmetic)  - default
+#   "rcp": multiply by the fp32 reciprocal, what ATen's GPU kernels do for a host-scalar divisor
+scale_mode = os.environ.get("PKV_SCALE_MODE", "div")
+
+# Read K/V of only the first head of each GQA group (the reference passes K/V already expanded by
+# repeat_kv, llama_model.py:158-159, so the other heads of a group are byte-identical copies).
+# Off by default: it is only valid when the caller really passes repeat_kv output.
+gqa_dedup = os.environ.get("PKV_GQA_DEDUP", "0") == "1"

@@ -1,0 +1,395 @@
+// pkv_api.hip — the C ABI of libpkv (see include/pkv.h): validation, workspace carving, launches,
+// optional per-kernel hipEvent timing.  No torch, no pybind; nothing here allocates device memory or
+// synchronises the device (pkv_prof_read waits on its own events only).
+#include "../../include/pkv.h"
+#include "pkv_kernels.hpp"
+
+#include <math.h>
+#include <mutex>
+#include <vector>
+
+using namespace pkv;
+
+namespace {
+
+thread_local int g_last_hip = 0;
+
+inline int hip_fail(hipError_t e) { g_last_hip = (int)e; return PKV_ERR_HIP; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+// ---- per-kernel timing -----------------------------------------------------------------------
+struct ProfRec { int id; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_pending;
+std::vector<hipEvent_t> g_free_events;
+double g_ms[PKV_K_COUNT] = {0};
+int64_t g_n[PKV_K_COUNT] = {0};
+
+hipEvent_t get_event() {
+  if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {
+  bool on; int id; hipStream_t st; hipEvent_t a, b;
+  ProfScope(int id_, hipStream_t st_) : on(g_prof_on), id(id_), st(st_) {
+    if (on) {
+      { std::lock_guard<std::mutex> lk(g_prof_mu); a = get_event(); b = get_event(); }
+      (void)hipEventRecord(a, st);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      (void)hipEventRecord(b, st);
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      g_pending.push_back({id, a, b});
+    }
+  }
+};
+
+// ---- validation ------------------------------------------------------------------------------
+int check_desc(const pkv_desc* d, bool need_topk) {
+  if (!d) return PKV_ERR_NULL;
+  if (d->dtype != PKV_BF16 && d->dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (d->D != 128) return PKV_ERR_SHAPE;
+  if (d->B < 1 || d->H < 1 || d->S < 2) return PKV_ERR_SHAPE;
+  if (d->kv_group < 1 || d->H % d->kv_group) return PKV_ERR_SHAPE;
+  if (d->window < 1 || d->window >= d->S) return PKV_ERR_SHAPE;
+  if (d->window > 64 || d->kv_group * d->window > 256) return PKV_ERR_UNSUPPORTED;
+  if (need_topk && (d->topk < 1 || d->topk > d->S - d->window)) return PKV_ERR_SHAPE;
+  if (d->pool_kind < 0 || d->pool_kind > 2) return PKV_ERR_SHAPE;
+  if (d->pool_kind != PKV_POOL_NONE) {
+    if (d->pool_kernel < 1 || !(d->pool_kernel & 1)) return PKV_ERR_SHAPE;
+    if (d->pool_kernel > 17) return PKV_ERR_UNSUPPORTED;
+  }
+  for (int i = 0; i < 3; ++i)
+    if ((d->q_stride[i] & 7) || (d->k_stride[i] & 7) || (d->v_stride[i] & 7)) return PKV_ERR_ALIGN;
+  if ((int64_t)d->B * d->H > 65535) return PKV_ERR_UNSUPPORTED;
+  return PKV_OK;
+}
+
+struct WsLayout {
+  int Sp, nT, Lp;
+  size_t off_logits, off_partial, off_scores, off_idx, off_rowstat, total;
+};
+
+WsLayout ws_layout(const pkv_desc* d) {
+  WsLayout w;
+  w.nT = (d->S + 255) / 256;
+  w.Sp = w.nT * 256;
+  w.Lp = (int)align_up((size_t)(d->S - d->window), 8);
+  const size_t rows = (size_t)d->B * d->H * d->window;
+  size_t o = 0;
+  w.off_logits = o;  o = align_up(o + rows * w.Sp * 2, 256);
+  w.off_partial = o; o = align_up(o + rows * w.nT * sizeof(float2), 256);
+  w.off_scores = o;  o = align_up(o + (size_t)d->B * d->H * w.Lp * 2, 256);
+  w.off_idx = o;     o = align_up(o + (size_t)d->B * d->H * (d->topk > 0 ? d->topk : 1) * 4, 256);
+  w.off_rowstat = o; o = align_up(o + (size_t)d->B * d->H * d->S * sizeof(float2), 256);   // H2O only
+  w.total = o;
+  return w;
+}
+
+int do_score_window(const pkv_desc* d, const void* q, const void* k, void* scores, int64_t stride,
+                    char* ws, const WsLayout& L, hipStream_t st) {
+  LogitsParams lp;
+  lp.q = q; lp.k = k;
+  lp.logits = ws + L.off_logits;
+  lp.partial = reinterpret_cast<float2*>(ws + L.off_partial);
+  lp.B = d->B; lp.H = d->H; lp.S = d->S; lp.w = d->window; lp.G = d->kv_group;
+  lp.Sp = L.Sp; lp.nT = L.nT;
+  lp.qs_b = d->q_stride[0]; lp.qs_h = d->q_stride[1]; lp.qs_s = d->q_stride[2];
+  lp.ks_b = d->k_stride[0]; lp.ks_h = d->k_stride[1]; lp.ks_s = d->k_stride[2];
+  lp.scale_mode = d->scale_mode;
+  lp.sqrt_d = (float)sqrt((double)d->D);   // math.sqrt(head_dim), cast to the fp32 opmath type
+  lp.rcp_sqrt_d = 1.0f / lp.sqrt_d;        // ATen GPU path: a * (1.0f / b)
+  {
+    ProfScope ps(PKV_K_LOGITS, st);
+    hipError_t e = launch_logits(d->dtype, lp, st);
+    if (e != hipSuccess) return hip_fail(e);
+  }
+  FinalizeParams fp;
+  fp.logits = lp.logits; fp.partial = lp.partial;
+  fp.scores = scores; fp.scores_stride = stride;
+  fp.B = d->B; fp.H = d->H; fp.S = d->S; fp.w = d->window; fp.Sp = L.Sp; fp.nT = L.nT;
+  fp.pool_kind = d->pool_kind;
+  fp.pool_kernel = d->pool_kind == PKV_POOL_NONE ? 1 : d->pool_kernel;
+  fp.reduce = d->reduce;
+  {
+    ProfScope ps(PKV_K_FINALIZE, st);
+    hipError_t e = launch_finalize(d->dtype, fp, st);
+    if (e != hipSuccess) return hip_fail(e);
+  }
+  return PKV_OK;
+}
+
+int do_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores, int64_t stride,
+                 char* ws, const WsLayout& L, hipStream_t st) {
+  H2OParams hp;
+  hp.q = q; hp.k = k;
+  hp.rowstat = reinterpret_cast<float2*>(ws + L.off_rowstat);
+  hp.scores = scores; hp.scores_stride = stride;
+  hp.B = d->B; hp.H = d->H; hp.S = d->S; hp.w = d->window; hp.G = d->kv_group;
+  hp.qs_b = d->q_stride[0]; hp.qs_h = d->q_stride[1]; hp.qs_s = d->q_stride[2];
+  hp.ks_b = d->k_stride[0]; hp.ks_h = d->k_stride[1]; hp.ks_s = d->k_stride[2];
+  hp.scale_mode = d->scale_mode;
+  hp.sqrt_d = (float)sqrt((double)d->D);
+  hp.rcp_sqrt_d = 1.0f / hp.sqrt_d;
+  {
+    ProfScope ps(PKV_K_H2O_STATS, st);
+    hipError_t e = launch_h2o_stats(d->dtype, hp, st);
+    if (e != hipSuccess) return hip_fail(e);
+  }
+  {
+    ProfScope ps(PKV_K_H2O_COLSUM, st);
+    hipError_t e = launch_h2o_colsum(d->dtype, hp, st);
+    if (e != hipSuccess) return hip_fail(e);
+  }
+  return PKV_OK;
+}
+
+int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t stride, const int32_t* kpr,
+            int32_t* idx, int64_t idx_stride, hipStream_t st) {
+  if (L < 1 || k < 1 || k > L || rows < 1) return PKV_ERR_SHAPE;
+  TopkParams tp;
+  tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
+  tp.idx_out = idx; tp.idx_stride = idx_stride;
+  const size_t lds = topk_lds_bytes(L, k, &tp.Lw, &tp.kpad);
+  if (lds > 160 * 1024 || 16 * (size_t)tp.Lw > 65536) return PKV_ERR_UNSUPPORTED;
+  ProfScope ps(PKV_K_TOPK, st);
+  hipError_t e = launch_topk(dtype, rows, tp, lds, st);
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+GatherParams make_gather(const pkv_desc* d, const void* k, const void* v, void* ko, void* vo) {
+  GatherParams g;
+  g.kptr = k; g.vptr = v; g.k_out = ko; g.v_out = vo;
+  g.idx = nullptr; g.idx_stride = 0; g.head_k = nullptr; g.cu_rows = nullptr;
+  g.B = d->B; g.H = d->H; g.S = d->S; g.w = d->window; g.nsel = d->topk; g.G = d->kv_group;
+  g.ks_b = d->k_stride[0]; g.ks_h = d->k_stride[1]; g.ks_s = d->k_stride[2];
+  g.vs_b = d->v_stride[0]; g.vs_h = d->v_stride[1]; g.vs_s = d->v_stride[2];
+  return g;
+}
+
+int do_gather(const GatherParams& g, int max_rows, hipStream_t st) {
+  ProfScope ps(PKV_K_GATHER, st);
+  hipError_t e = launch_gather(g, max_rows, st);
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
+                    void* v_out, int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  if (!q || !k || !v || !k_out || !v_out || !ws) return PKV_ERR_NULL;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out) || misaligned(ws))
+    return PKV_ERR_ALIGN;
+  WsLayout L = ws_layout(d);
+  if (ws_bytes < (h2o ? L.total : L.off_rowstat)) return PKV_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* w = static_cast<char*>(ws);
+  void* scores = w + L.off_scores;
+  rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st);
+  if (rc) return rc;
+  int32_t* idx = idx_out ? idx_out : reinterpret_cast<int32_t*>(w + L.off_idx);
+  rc = do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx, d->topk, st);
+  if (rc) return rc;
+  GatherParams g = make_gather(d, k, v, k_out, v_out);
+  g.idx = idx; g.idx_stride = d->topk;
+  return do_gather(g, d->topk + d->window, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pkv_version(void) { return PKV_VERSION; }
+
+const char* pkv_strerror(int s) {
+  switch (s) {
+    case PKV_OK: return "ok";
+    case PKV_ERR_DTYPE: return "unsupported dtype (need bf16 or fp16)";
+    case PKV_ERR_SHAPE: return "bad shape / parameter out of range";
+    case PKV_ERR_ALIGN: return "pointer or stride breaks 16-byte row alignment";
+    case PKV_ERR_WORKSPACE: return "workspace too small";
+    case PKV_ERR_UNSUPPORTED: return "request outside the limits of this build";
+    case PKV_ERR_HIP: return "HIP runtime error";
+    case PKV_ERR_NULL: return "null pointer";
+    default: return "unknown status";
+  }
+}
+
+int pkv_last_hip_error(void) { return g_last_hip; }
+
+size_t pkv_workspace_bytes(const pkv_desc* d) {
+  if (!d || d->S < 2 || d->window < 1 || d->window >= d->S || d->B < 1 || d->H < 1) return 0;
+  return ws_layout(d).total;
+}
+
+int pkv_score_window(const pkv_desc* d, const void* q, const void* k, void* scores_out,
+                     int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  int rc = check_desc(d, false);
+  if (rc) return rc;
+  if (!q || !k || !scores_out || !ws) return PKV_ERR_NULL;
+  if (misaligned(q) || misaligned(k) || misaligned(scores_out) || misaligned(ws)) return PKV_ERR_ALIGN;
+  WsLayout L = ws_layout(d);
+  if (ws_bytes < L.off_scores) return PKV_ERR_WORKSPACE;
+  if ((scores_stride & 7) || scores_stride < L.Lp) return PKV_ERR_ALIGN;
+  return do_score_window(d, q, k, scores_out, scores_stride, static_cast<char*>(ws), L, static_cast<hipStream_t>(stream));
+}
+
+int pkv_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores_out,
+                  int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  int rc = check_desc(d, false);
+  if (rc) return rc;
+  if (!q || !k || !scores_out || !ws) return PKV_ERR_NULL;
+  if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
+  WsLayout L = ws_layout(d);
+  if (ws_bytes < L.total) return PKV_ERR_WORKSPACE;
+  if (scores_stride < d->S - d->window) return PKV_ERR_SHAPE;
+  return do_score_h2o(d, q, k, scores_out, scores_stride, static_cast<char*>(ws), L, static_cast<hipStream_t>(stream));
+}
+
+int pkv_topk(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores, int64_t scores_stride,
+             const int32_t* k_per_row, int32_t* idx_out, int64_t idx_stride, pkv_stream_t stream) {
+  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (!scores || !idx_out) return PKV_ERR_NULL;
+  if (scores_stride < L || idx_stride < k) return PKV_ERR_SHAPE;
+  return do_topk(dtype, rows, L, k, scores, scores_stride, k_per_row, idx_out, idx_stride, static_cast<hipStream_t>(stream));
+}
+
+int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx,
+                       int64_t idx_stride, void* k_out, void* v_out, pkv_stream_t stream) {
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  if (!k || !v || !idx || !k_out || !v_out) return PKV_ERR_NULL;
+  if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out)) return PKV_ERR_ALIGN;
+  if (idx_stride < d->topk) return PKV_ERR_SHAPE;
+  GatherParams g = make_gather(d, k, v, k_out, v_out);
+  g.idx = idx; g.idx_stride = idx_stride;
+  return do_gather(g, d->topk + d->window, static_cast<hipStream_t>(stream));
+}
+
+int pkv_gather_streaming(const pkv_desc* d, const void* k, const void* v, void* k_out, void* v_out,
+                         pkv_stream_t stream) {
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  if (!k || !v || !k_out || !v_out) return PKV_ERR_NULL;
+  if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out)) return PKV_ERR_ALIGN;
+  GatherParams g = make_gather(d, k, v, k_out, v_out);   // idx == nullptr: rows 0..k-1 (:607-608)
+  return do_gather(g, d->topk + d->window, static_cast<hipStream_t>(stream));
+}
+
+int pkv_compress(const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out, void* v_out,
+                 int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  return compress_common(false, d, q, k, v, k_out, v_out, idx_out, ws, ws_bytes, stream);
+}
+
+int pkv_compress_h2o(const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out, void* v_out,
+                     int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  return compress_common(true, d, q, k, v, k_out, v_out, idx_out, ws, ws_bytes, stream);
+}
+
+int pkv_sort_rows(int32_t dtype, int32_t rows, int32_t L, const void* scores, int64_t scores_stride,
+                  int32_t* sorted_idx, void* sorted_val, pkv_stream_t stream) {
+  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (!scores || !sorted_idx) return PKV_ERR_NULL;
+  if (rows < 1 || L < 1 || scores_stride < L) return PKV_ERR_SHAPE;
+  if (L > 32768) return PKV_ERR_UNSUPPORTED;
+  SortParams sp;
+  sp.scores = scores; sp.scores_stride = scores_stride; sp.L = L;
+  sp.n = 2; while (sp.n < L) sp.n <<= 1;
+  sp.sorted_idx = sorted_idx; sp.sorted_val = sorted_val;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(PKV_K_SORT, st);
+  hipError_t e = launch_sort_rows(dtype, rows, sp, st);
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, int32_t base_capacity,
+                   double floor_ratio, int32_t normalize, int32_t* head_capacity, void* ws,
+                   size_t ws_bytes, pkv_stream_t stream) {
+  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (!sorted_val || !head_capacity || !ws) return PKV_ERR_NULL;
+  if (H < 1 || H > 256 || L < 1 || base_capacity < 1 || base_capacity > L) return PKV_ERR_SHAPE;
+  if (ws_bytes < 1024 + (size_t)2 * H * 256 * 4) return PKV_ERR_WORKSPACE;
+  BudgetParams bp;
+  bp.sorted_val = sorted_val; bp.H = H; bp.L = L; bp.base = base_capacity;
+  bp.one_minus_floor = (float)(1.0 - floor_ratio);                    // python double, then the fp32 scalar of :719
+  bp.floor_capacity = (int)((double)base_capacity * floor_ratio);     // int(base_capacity * floor_ratio) (:632)
+  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(PKV_K_BUDGET, st);
+  hipError_t e = launch_budget(dtype, bp, st);
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, int32_t* head_lens,
+                     int32_t* cu_klen, pkv_stream_t stream) {
+  if (!head_capacity || !head_lens || !cu_klen) return PKV_ERR_NULL;
+  if (H < 1) return PKV_ERR_SHAPE;
+  hipError_t e = launch_ada_metadata(H, window, head_capacity, head_lens, cu_klen, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32_t* sorted_idx,
+                    int64_t idx_stride, const int32_t* head_capacity, const int32_t* cu_klen,
+                    void* k_out, void* v_out, pkv_stream_t stream) {
+  int rc = check_desc(d, false);
+  if (rc) return rc;
+  if (d->B != 1) return PKV_ERR_SHAPE;   // reference asserts bsz == 1 (:724)
+  if (!k || !v || !sorted_idx || !head_capacity || !cu_klen || !k_out || !v_out) return PKV_ERR_NULL;
+  if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out)) return PKV_ERR_ALIGN;
+  GatherParams g = make_gather(d, k, v, k_out, v_out);
+  g.idx = sorted_idx; g.idx_stride = idx_stride; g.head_k = head_capacity; g.cu_rows = cu_klen;
+  // worst case rows per head: d->topk if the caller knows max(cap_h), else every past token
+  const int max_sel = d->topk > 0 ? d->topk : d->S - d->window;
+  return do_gather(g, max_sel + d->window, static_cast<hipStream_t>(stream));
+}
+
+int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const void* cache, const void* state,
+                            const int32_t* head_lens, const int32_t* cu_klen, void* out, pkv_stream_t stream) {
+  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (!cache || !state || !head_lens || !cu_klen || !out) return PKV_ERR_NULL;
+  if (H < 1 || head_dim < 8 || (head_dim & 7)) return PKV_ERR_SHAPE;
+  if (misaligned(cache) || misaligned(state) || misaligned(out)) return PKV_ERR_ALIGN;
+  FlattenParams fp;
+  fp.cache = cache; fp.state = state; fp.head_lens = head_lens; fp.cu_klen = cu_klen; fp.out = out;
+  fp.H = H; fp.row_bytes = head_dim * 2;
+  hipError_t e = launch_flatten(fp, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int pkv_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  const int prev = g_prof_on ? 1 : 0;
+  g_prof_on = on != 0;
+  return prev;
+}
+
+int pkv_prof_read(double* ms_sum, int64_t* launches, int reset) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_pending) {
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e != hipSuccess) return hip_fail(e);
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(e);
+    g_ms[r.id] += ms;
+    g_n[r.id] += 1;
+    g_free_events.push_back(r.a);
+    g_free_events.push_back(r.b);
+  }
+  g_pending.clear();
+  for (int i = 0; i < PKV_K_COUNT; ++i) {
+    if (ms_sum) ms_sum[i] = g_ms[i];
+    if (launches) launches[i] = g_n[i];
+    if (reset) { g_ms[i] = 0; g_n[i] = 0; }
+  }
+  return PKV_OK;
+}
+
+}  // extern "C"

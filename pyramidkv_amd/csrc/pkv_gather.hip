@@ -1,0 +1,100 @@
+// pkv_gather.hip — K/V gather-compaction (gfx950).
+//
+//   gather_kernel   reference pyramidkv_utils.py:335,341-346 (dense [B,H,k+w,D]),
+//                   :607-620 (StreamingLLM: identity indices), :733-757 (AdaKV/HeadKV flat var-len)
+//   flatten_kernel  reference csrc/csrc/cuda_api.cu:11-53 (decode-time flat-cache append)
+//
+// Pure data movement, bit-exact.  Roofline: HBM.  Algorithmic bytes per call
+//   4 * (k+w) * D * e * B * H     (K and V, read + write).
+// A head-row is D*e = 256 B = 16 lanes x 16 B; a wavefront moves 4 rows per instruction, every lane
+// keeps 8 independent 16-B loads in flight (4 rows x {K,V}); writes are fully sequential per head.
+#include "pkv_common.hpp"
+#include "pkv_kernels.hpp"
+
+namespace pkv {
+
+constexpr int GA_ROWS = 64;   // output rows per workgroup (x2 tensors)
+
+__global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
+  const int tid = threadIdx.x;
+  const int chunk = tid & 15;          // 16-B chunk of the 256-B row
+  const int slot = tid >> 4;           // 16 row slots
+  const int bh = blockIdx.y;
+  const int b = bh / p.H;
+  const int h = bh - b * p.H;
+  const int hk = h / p.G;
+  const int L = p.S - p.w;
+  const int nsel = p.head_k ? p.head_k[bh] : p.nsel;
+  const int nrows = nsel + p.w;
+  const int r_blk = blockIdx.x * GA_ROWS;
+  if (r_blk >= nrows) return;
+  const int64_t out_row0 = p.cu_rows ? (int64_t)p.cu_rows[bh] : (int64_t)bh * nrows;
+
+  const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h + chunk * 8;
+  const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.vptr) + (int64_t)b * p.vs_b + (int64_t)hk * p.vs_h + chunk * 8;
+  const int32_t* ib = p.idx ? p.idx + (int64_t)bh * p.idx_stride : nullptr;
+
+  int src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r_blk + j * 16 + slot;
+    int s = -1;
+    if (r < nsel) s = ib ? ib[r] : r;
+    else if (r < nrows) s = L + (r - nsel);
+    src[j] = s;
+  }
+  uint4 kd[4], vd[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (src[j] >= 0) {
+      kd[j] = *reinterpret_cast<const uint4*>(kb + (int64_t)src[j] * p.ks_s);
+      vd[j] = *reinterpret_cast<const uint4*>(vb + (int64_t)src[j] * p.vs_s);
+    }
+  }
+  uint16_t* ko = reinterpret_cast<uint16_t*>(p.k_out) + chunk * 8;
+  uint16_t* vo = reinterpret_cast<uint16_t*>(p.v_out) + chunk * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (src[j] >= 0) {
+      const int64_t orow = out_row0 + r_blk + j * 16 + slot;
+      *reinterpret_cast<uint4*>(ko + orow * 128) = kd[j];
+      *reinterpret_cast<uint4*>(vo + orow * 128) = vd[j];
+    }
+  }
+}
+
+hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st) {
+  dim3 grid((max_rows + GA_ROWS - 1) / GA_ROWS, p.B * p.H);
+  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode-time flat-cache append.  grid = (H, FL_SPLIT); 16-byte vector copies; one inserting block.
+// ------------------------------------------------------------------------------------------------
+constexpr int FL_SPLIT = 32;
+
+__global__ __launch_bounds__(256) void flatten_kernel(FlattenParams p) {
+  const int h = blockIdx.x;
+  const int n = p.head_lens[h];
+  const int64_t src_row = p.cu_klen[h];
+  const int64_t dst_row = src_row + h;                 // cuda_api.cu:28
+  const int64_t ins_row = (int64_t)p.cu_klen[h + 1] + h;  // cuda_api.cu:29
+  const int64_t units = (int64_t)n * p.row_bytes / 16;
+  const uint4* s = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.cache) + src_row * p.row_bytes);
+  uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out) + dst_row * p.row_bytes);
+  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < units; i += (int64_t)FL_SPLIT * 256) d[i] = s[i];
+  if (blockIdx.y == 0) {
+    const int ru = p.row_bytes / 16;
+    const uint4* st = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.state) + (int64_t)h * p.row_bytes);
+    uint4* di = reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out) + ins_row * p.row_bytes);
+    for (int i = threadIdx.x; i < ru; i += 256) di[i] = st[i];
+  }
+}
+
+hipError_t launch_flatten(const FlattenParams& p, hipStream_t st) {
+  hipLaunchKernelGGL(flatten_kernel, dim3(p.H, FL_SPLIT), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace pkv

@@ -1,0 +1,107 @@
+// pkv_kernels.hpp — kernel parameter blocks and launch prototypes (internal to libpkv).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pkv {
+
+struct LogitsParams {
+  const void* q;
+  const void* k;
+  void* logits;      // [B*H*w][Sp] model dtype
+  float2* partial;   // [B*H*w][nT] (tile row max, tile sum exp)
+  int B, H, S, w, G; // G = kv_group
+  int Sp, nT;
+  int64_t qs_b, qs_h, qs_s;
+  int64_t ks_b, ks_h, ks_s;
+  int scale_mode;
+  float sqrt_d, rcp_sqrt_d;
+};
+
+struct FinalizeParams {
+  const void* logits;
+  const float2* partial;
+  void* scores;          // [B*H][scores_stride]
+  int64_t scores_stride;
+  int B, H, S, w, Sp, nT;
+  int pool_kind, pool_kernel, reduce;
+};
+
+struct TopkParams {
+  const void* scores;    // [rows][scores_stride] model dtype
+  int64_t scores_stride;
+  int L, k;
+  const int32_t* k_per_row;
+  int32_t* idx_out;      // [rows][idx_stride]
+  int64_t idx_stride;
+  int Lw;                // keys per wave (multiple of 512)
+  int kpad;              // power of two >= k (bitonic path) or k (rank path)
+};
+
+struct SortParams {
+  const void* scores;
+  int64_t scores_stride;
+  int L, n;              // n = power of two >= L
+  int32_t* sorted_idx;   // [rows][L]
+  void* sorted_val;      // [rows][L] or null
+};
+
+struct GatherParams {
+  const void* kptr;
+  const void* vptr;
+  void* k_out;
+  void* v_out;
+  const int32_t* idx;        // [B*H][idx_stride] or null (identity: StreamingLLM)
+  int64_t idx_stride;
+  const int32_t* head_k;     // per-(b,h) selected count (flat layout) or null -> uniform k
+  const int32_t* cu_rows;    // per-(b,h) first output row (flat layout) or null -> bh*(k+w)
+  int B, H, S, w, nsel, G;   // nsel = uniform selected-row count k
+  int64_t ks_b, ks_h, ks_s;
+  int64_t vs_b, vs_h, vs_s;
+};
+
+struct BudgetParams {
+  const void* sorted_val;    // [H][L] descending
+  int H, L, base;
+  float one_minus_floor;     // (float)(1.0 - floor_ratio), the fp32 scalar ATen multiplies by
+  int floor_capacity;        // int(base * floor_ratio)
+  int normalize;
+  int32_t* head_capacity;    // [H]
+  void* ws;                  // 1024 B ratios + 2 * H*256 int32
+};
+
+struct FlattenParams {
+  const void* cache;
+  const void* state;
+  const int32_t* head_lens;
+  const int32_t* cu_klen;
+  void* out;
+  int H, row_bytes;
+};
+
+struct H2OParams {
+  const void* q;
+  const void* k;
+  float2* rowstat;    // [B*H][S] (row max, row sum of exp)
+  void* scores;
+  int64_t scores_stride;
+  int B, H, S, w, G;
+  int64_t qs_b, qs_h, qs_s;
+  int64_t ks_b, ks_h, ks_s;
+  int scale_mode;
+  float sqrt_d, rcp_sqrt_d;
+};
+
+hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st);
+hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st);
+size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out);
+hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st);
+hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);
+hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
+hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
+hipError_t launch_ada_metadata(int H, int w, const int32_t* cap, int32_t* head_lens, int32_t* cu_klen, hipStream_t st);
+hipError_t launch_flatten(const FlattenParams& p, hipStream_t st);
+hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st);
+hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st);
+
+}  // namespace pkv

@@ -1,0 +1,272 @@
+// pkv_score.hip — observation-window score kernels (gfx950).
+//
+//   logits_kernel    reference pyramidkv_utils.py:317-324  (Q[-w:] K^T / sqrt(D), corner mask)
+//                    + per-tile softmax partials (row max, sum of exp) so K is read exactly once
+//   finalize_kernel  reference :326-333  (fp32 softmax -> model dtype, window-row sum/mean -> model
+//                    dtype, avg/max pool)
+//
+// Roofline: HBM.  Algorithmic bytes per (b,h): S*D*e for K (the dominant term; /kv_group when the
+// caller hands over un-expanded GQA K) + w*D*e for Q.  Logits [w][S] (1/16 of K at w=8) make one
+// round trip through L2/MALL between the two kernels.
+#include "pkv_common.hpp"
+#include "pkv_kernels.hpp"
+
+namespace pkv {
+
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8_t;
+
+template <typename T> struct Mfma;
+template <> struct Mfma<BF16> {
+  static __device__ __forceinline__ f32x4 run(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<F16> {
+  static __device__ __forceinline__ f32x4 run(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// logits_kernel: one workgroup = 256 keys of one (batch, kv-head group); 4 waves x 64 keys.
+// MFMA 16x16x32: A = 16 keys x 32 d (K tile, rows), B = 32 d x 16 columns (window queries).
+// A column c of the group is (head h0 + c / w, window row c % w); C = kv_group * w columns.
+// D element [key i][col j] sits in lane (j + 16*(i/4)), register i%4.
+// ------------------------------------------------------------------------------------------------
+constexpr int LG_TILE = 256;              // keys per workgroup
+constexpr int LG_LROW = LG_TILE + 8;      // LDS row stride in elements (528 B: 16-B aligned, <=2-way write conflicts)
+
+template <typename T>
+__global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint16_t* tile = reinterpret_cast<uint16_t*>(smem_raw);  // [C][LG_LROW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_idx = blockIdx.x;                 // key tile
+  const int grp = blockIdx.y;                   // b * (H/G) + kv head
+  const int HG = p.H / p.G;
+  const int b = grp / HG;
+  const int hk = grp - b * HG;
+  const int h0 = hk * p.G;
+  const int w = p.w;
+  const int C = p.G * w;
+  const int S = p.S;
+  const int L = S - w;
+
+  const int li = lane & 15;   // key within 16-subtile (A rows) / column within 16-tile (B cols)
+  const int lg = lane >> 4;   // 8-element d-chunk within a 32-wide k-step
+
+  // ---- issue all K loads of this wave: 4 subtiles x 4 k-steps x 16 B per lane ----
+  const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
+  const int s_wave = t_idx * LG_TILE + wave * 64;
+  uint4 kf[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int s = s_wave + t * 16 + li;
+    s = s < S ? s : S - 1;  // clamp: stay in bounds; out-of-range keys are masked out of the stats below
+    const uint16_t* row = kbase + (int64_t)s * p.ks_s + lg * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) kf[t][kk] = *reinterpret_cast<const uint4*>(row + kk * 32);
+  }
+
+  const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b;
+  const float fmin_v = Elem<T>::finfo_min();
+  const int ntile_c = (C + 15) >> 4;
+
+  for (int n = 0; n < ntile_c; ++n) {
+    // B fragments: column c = n*16 + li -> Q[b, h0 + c/w, S - w + c%w, kk*32 + lg*8 ..]
+    const int c = n * 16 + li;
+    uint4 qf[4];
+    if (c < C) {
+      const int hh = h0 + c / w;
+      const int rr = c - (c / w) * w;
+      const uint16_t* qrow = qb + (int64_t)hh * p.qs_h + (int64_t)(L + rr) * p.qs_s + lg * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const uint4*>(qrow + kk * 32);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) qf[kk] = make_uint4(0, 0, 0, 0);
+    }
+    const int rr_c = c % w;  // window row of this lane's column
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(kf[t][kk], qf[kk], acc);
+      // epilogue: three roundings to the model dtype, as the reference materialises them
+      const int key0 = wave * 64 + t * 16 + lg * 4;        // key within the tile of acc[0]
+      const int sg0 = t_idx * LG_TILE + key0;              // global key index
+      uint16_t o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = Elem<T>::to_f32(Elem<T>::from_f32(acc[r]));                     // matmul output dtype (:317)
+        x = (p.scale_mode == 0) ? (x / p.sqrt_d) : (x * p.rcp_sqrt_d);            // "/ math.sqrt(head_dim)" (:317)
+        uint16_t y = Elem<T>::from_f32(x);
+        const int s = sg0 + r;
+        if (s >= L && (s - L) > rr_c)                                              // strict upper corner (:318-324)
+          y = Elem<T>::from_f32(Elem<T>::to_f32(y) + fmin_v);
+        o[r] = y;
+      }
+      if (c < C) {
+        uint2 pk;
+        pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        *reinterpret_cast<uint2*>(tile + c * LG_LROW + key0) = pk;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- per-row tile statistics + coalesced 16-B store of the logits tile ----
+  const int64_t rowbase = ((int64_t)b * p.H + h0) * w;
+  uint16_t* lg_out = reinterpret_cast<uint16_t*>(p.logits);
+  const int items = C * 32;  // 32 chunks of 8 keys per row
+  for (int it = tid; it < items; it += 256) {
+    const int row = it >> 5;
+    const int chunk = it & 31;
+    U4 u;
+    u.v = *reinterpret_cast<const uint4*>(tile + row * LG_LROW + chunk * 8);
+    const int s0 = t_idx * LG_TILE + chunk * 8;
+    float xv[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xv[e] = Elem<T>::to_f32(u.h[e]);
+      if (s0 + e < S) m = fmaxf(m, xv[e]);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));   // 32-lane half = one row
+    float l = 0.f;
+    if (m != -INFINITY) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (s0 + e < S) l += expf(xv[e] - m);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    if (chunk == 0) p.partial[(rowbase + row) * p.nT + t_idx] = make_float2(m, l);
+    *reinterpret_cast<uint4*>(lg_out + (rowbase + row) * (int64_t)p.Sp + s0) = u.v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize_kernel: one workgroup = 2032 output positions (+8 halo each side) of one (b,h).
+// ------------------------------------------------------------------------------------------------
+constexpr int FN_SPAN = 2048;              // positions computed per workgroup (256 threads x 8)
+constexpr int FN_OUT = FN_SPAN - 16;       // positions written per workgroup
+
+template <typename T>
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
+  __shared__ __attribute__((aligned(16))) uint16_t sc[FN_SPAN];
+  __shared__ float rowM[64];
+  __shared__ float rowS[64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int bh = blockIdx.y;
+  const int w = p.w;
+  const int L = p.S - w;
+  const int64_t rowbase = (int64_t)bh * w;
+
+  // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M)
+  for (int r = wave; r < w; r += 4) {
+    const float2* pr = p.partial + (rowbase + r) * p.nT;
+    float m = -INFINITY;
+    for (int t = lane; t < p.nT; t += 64) m = fmaxf(m, pr[t].x);
+    m = wave_max(m);
+    float z = 0.f;
+    for (int t = lane; t < p.nT; t += 64) {
+      const float2 v = pr[t];
+      if (v.x != -INFINITY) z += v.y * expf(v.x - m);
+    }
+    z = wave_sum(z);
+    if (lane == 0) { rowM[r] = m; rowS[r] = z; }
+  }
+  __syncthreads();
+
+  const int r0 = blockIdx.x * FN_OUT - 8;
+  const int s0 = r0 + tid * 8;
+  const uint16_t pad = (p.pool_kind == 2) ? Elem<T>::neg_inf() : (uint16_t)0;
+  U4 outv;
+  if (s0 >= 0 && s0 < L) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const uint16_t* lgp = reinterpret_cast<const uint16_t*>(p.logits) + rowbase * (int64_t)p.Sp + s0;
+    for (int r = 0; r < w; ++r) {
+      U4 u;
+      u.v = *reinterpret_cast<const uint4*>(lgp + (int64_t)r * p.Sp);
+      const float M = rowM[r], Z = rowS[r];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pr = expf(Elem<T>::to_f32(u.h[e]) - M) / Z;                 // fp32 softmax (:326)
+        acc[e] += Elem<T>::to_f32(Elem<T>::from_f32(pr));                       // .to(dtype), fp32 row accumulate (:327)
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (p.reduce == 1) ? (acc[e] / (float)w) : acc[e];           // mean (:661) or sum (:327)
+      outv.h[e] = (s0 + e < L) ? Elem<T>::from_f32(v) : pad;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) outv.h[e] = pad;
+  }
+  *reinterpret_cast<uint4*>(sc + tid * 8) = outv.v;
+  __syncthreads();
+
+  if (tid == 0 || tid == 255 || s0 >= L) return;   // halo threads / nothing to write
+  U4 res;
+  const int half = p.pool_kernel >> 1;
+  if (p.pool_kind == 0) {
+    res = outv;
+  } else if (p.pool_kind == 2) {                                                 // max_pool1d, -inf padding (:331)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = tid * 8 + e;
+      float m = -INFINITY;
+      for (int j = -half; j <= half; ++j) m = fmaxf(m, Elem<T>::to_f32(sc[c + j]));
+      res.h[e] = Elem<T>::from_f32(m);
+    }
+  } else {                                                                       // avg_pool1d, zero padding, / kernel (:329)
+    const float ks = (float)p.pool_kernel;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = tid * 8 + e;
+      float sum = 0.f;
+      for (int j = -half; j <= half; ++j) sum += Elem<T>::to_f32(sc[c + j]);
+      res.h[e] = Elem<T>::from_f32(sum / ks);
+    }
+  }
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride + s0;
+  *reinterpret_cast<uint4*>(out) = res.v;   // stride % 8 == 0 and stride >= roundup(L,8): in bounds
+}
+
+template __global__ void logits_kernel<BF16>(LogitsParams);
+template __global__ void logits_kernel<F16>(LogitsParams);
+template __global__ void finalize_kernel<BF16>(FinalizeParams);
+template __global__ void finalize_kernel<F16>(FinalizeParams);
+
+hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
+  const int C = p.G * p.w;
+  dim3 grid(p.nT, p.B * (p.H / p.G));
+  size_t lds = (size_t)C * LG_LROW * sizeof(uint16_t);
+  if (dtype == 0) hipLaunchKernelGGL(logits_kernel<BF16>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(logits_kernel<F16>, grid, dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st) {
+  const int L = p.S - p.w;
+  dim3 grid((L + FN_OUT - 1) / FN_OUT, p.B * p.H);
+  if (dtype == 0) hipLaunchKernelGGL(finalize_kernel<BF16>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(finalize_kernel<F16>, grid, dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace pkv

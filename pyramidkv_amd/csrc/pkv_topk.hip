@@ -1,0 +1,296 @@
+// pkv_topk.hip — token selection kernels (gfx950).
+//
+//   topk_kernel       reference pyramidkv_utils.py:334 (:238,:270,:562)  scores.topk(k).indices
+//   sort_rows_kernel  reference :706  attn_score.sort(dim=-1, descending=True)   (AdaKV/HeadKV)
+//
+// Order is pinned to (value desc, index asc): what ATen's GPU topk/sort produce (radix select of the
+// k-th value, ">" then "==" in index order, stable block radix sort) and what oracle/topk_canonical
+// restates.  Scores are 16-bit; the whole score row of a head lives in LDS (S-w <= 65536 keys),
+// selection is an exact two-level (8+8 bit) radix select with bank-spread LDS counters, winners are
+// compacted with wavefront scans in index order and ordered in LDS.
+//
+// Roofline: one workgroup per (b,h) row, 2*L bytes read once from L2/HBM; the kernel is
+// latency/LDS-bound, not HBM-bound (64 KB per head at S=32k).
+#include "pkv_common.hpp"
+#include "pkv_kernels.hpp"
+
+namespace pkv {
+
+constexpr int TK_THREADS = 1024;
+constexpr int TK_WAVES = 16;
+constexpr int TK_CNT_WORDS = 256 * 32;   // counters[bin][lane&31], lo16 = lanes 0-31, hi16 = lanes 32-63
+constexpr int TK_RANK_MAX = 1024;        // k <= this: rank-by-counting; above: bitonic network
+
+size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out) {
+  int per_wave = (L + TK_WAVES - 1) / TK_WAVES;
+  int Lw = ((per_wave + 511) / 512) * 512;
+  if (Lw < 512) Lw = 512;
+  int kpad;
+  if (k <= TK_RANK_MAX) kpad = (k + 3) & ~3;
+  else { kpad = 1; while (kpad < k) kpad <<= 1; }
+  if (Lw_out) *Lw_out = Lw;
+  if (kpad_out) *kpad_out = kpad;
+  size_t xwords = (size_t)(kpad > TK_CNT_WORDS ? kpad : TK_CNT_WORDS);
+  return (size_t)2 * TK_WAVES * Lw + 4 * xwords + 4 * 256 + 4 * 64;
+}
+
+// sum the bank-spread counters into hist[256]
+__device__ __forceinline__ void reduce_counters(const uint32_t* X, uint32_t* hist, int tid) {
+  const int bin = tid >> 2, part = tid & 3;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t v = X[bin * 32 + part * 8 + i];
+    s += (v & 0xffffu) + (v >> 16);
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if (part == 0) hist[bin] = s;
+}
+
+// bin b with  above(b) < need <= above(b) + hist[b]  where above(b) = sum_{b'>b} hist[b']
+__device__ __forceinline__ void find_bin(const uint32_t* hist, uint32_t need, int* out_bin, int* out_above, int tid) {
+  if (tid < 256) {
+    uint32_t above = 0;
+    for (int b2 = tid + 1; b2 < 256; ++b2) above += hist[b2];
+    if (above < need && need <= above + hist[tid]) { *out_bin = tid; *out_above = (int)above; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int row = blockIdx.x;
+  const int L = p.L;
+  int k = p.k;
+  if (p.k_per_row) { const int kr = p.k_per_row[row]; k = kr < k ? kr : k; }
+  if (k <= 0) return;
+  if (k > L) k = L;
+
+  const int Lw = p.Lw;
+  const int Lk = TK_WAVES * Lw;
+  uint16_t* keys = reinterpret_cast<uint16_t*>(smem);
+  uint32_t* X = reinterpret_cast<uint32_t*>(smem + (size_t)2 * Lk);        // counters, later `sel`
+  const int xwords = p.kpad > TK_CNT_WORDS ? p.kpad : TK_CNT_WORDS;
+  uint32_t* hist = X + xwords;
+  int* misc = reinterpret_cast<int*>(hist + 256);
+  uint32_t* wcnt = reinterpret_cast<uint32_t*>(misc + 16);
+
+  const uint16_t* src = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)row * p.scores_stride;
+  const bool vec_ok = ((p.scores_stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
+  const uint32_t inc = lane < 32 ? 1u : 65536u;
+  const int cslot = lane & 31;
+  const int niter = Lw / 512;
+
+  for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X[i] = 0;
+  __syncthreads();
+
+  // ---- pass A: HBM/L2 -> ordered keys in LDS, histogram of the high byte ----
+  for (int j = 0; j < niter; ++j) {
+    const int base = wave * Lw + j * 512 + lane * 8;
+    U4 u;
+    if (vec_ok && base + 8 <= L) {
+      u.v = *reinterpret_cast<const uint4*>(src + base);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u.h[e] = (base + e < L) ? src[base + e] : (uint16_t)0;
+    }
+    U4 ko;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool valid = base + e < L;
+      const uint32_t key = valid ? order_key<T>(u.h[e]) : 0u;
+      ko.h[e] = (uint16_t)key;
+      if (valid) atomicAdd(&X[(key >> 8) * 32 + cslot], inc);
+    }
+    *reinterpret_cast<uint4*>(keys + base) = ko.v;
+  }
+  __syncthreads();
+  reduce_counters(X, hist, tid);
+  __syncthreads();
+  find_bin(hist, (uint32_t)k, &misc[0], &misc[1], tid);
+  __syncthreads();
+  const uint32_t b1 = (uint32_t)misc[0];
+  const int n_above1 = misc[1];
+
+  // ---- pass B: histogram of the low byte inside bin b1 ----
+  for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X[i] = 0;
+  __syncthreads();
+  for (int j = 0; j < niter; ++j) {
+    const int base = wave * Lw + j * 512 + lane * 8;
+    U4 kv;
+    kv.v = *reinterpret_cast<const uint4*>(keys + base);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t key = kv.h[e];
+      if (key != 0u && (key >> 8) == b1) atomicAdd(&X[(key & 255u) * 32 + cslot], inc);
+    }
+  }
+  __syncthreads();
+  reduce_counters(X, hist, tid);
+  __syncthreads();
+  find_bin(hist, (uint32_t)(k - n_above1), &misc[2], &misc[3], tid);
+  __syncthreads();
+  const uint32_t Tkey = (b1 << 8) | (uint32_t)misc[2];
+  const int n_gt = n_above1 + misc[3];          // keys strictly above the threshold
+  const int n_eq_take = k - n_gt;               // lowest-index keys equal to the threshold
+
+  // ---- pass C: per-wave (gt, eq) counts so that compaction keeps index order ----
+  {
+    uint32_t cg = 0, ce = 0;
+    for (int j = 0; j < niter; ++j) {
+      const int base = wave * Lw + j * 512 + lane * 8;
+      U4 kv;
+      kv.v = *reinterpret_cast<const uint4*>(keys + base);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t key = kv.h[e];
+        cg += key > Tkey;
+        ce += key == Tkey;
+      }
+    }
+    cg = wave_sum_u32(cg);
+    ce = wave_sum_u32(ce);
+    if (lane == 0) { wcnt[wave] = cg; wcnt[16 + wave] = ce; }
+  }
+  __syncthreads();   // also: every read of the counters in X is done; X becomes `sel`
+  uint32_t run_g = 0, run_e = 0;
+  for (int w2 = 0; w2 < wave; ++w2) { run_g += wcnt[w2]; run_e += wcnt[16 + w2]; }
+  uint32_t* sel = X;
+
+  // ---- pass D: compaction.  composite = key<<16 | (0xffff - index): descending composite order
+  //      == (value desc, index asc) ----
+  for (int j = 0; j < niter; ++j) {
+    const int base = wave * Lw + j * 512 + lane * 8;
+    U4 kv;
+    kv.v = *reinterpret_cast<const uint4*>(keys + base);
+    uint32_t cg = 0, ce = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t key = kv.h[e];
+      cg += key > Tkey;
+      ce += key == Tkey;
+    }
+    const uint32_t packed = (ce << 16) | cg;      // per-iteration totals <= 512 each
+    const uint32_t incl = wave_incl_scan_u32(packed);
+    const uint32_t excl = incl - packed;
+    uint32_t og = run_g + (excl & 0xffffu);
+    uint32_t oe = run_e + (excl >> 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t key = kv.h[e];
+      const uint32_t comp = (key << 16) | (0xffffu - (uint32_t)(base + e));
+      if (key > Tkey) {
+        sel[og++] = comp;
+      } else if (key == Tkey) {
+        if ((int)oe < n_eq_take) sel[n_gt + oe] = comp;
+        ++oe;
+      }
+    }
+    const uint32_t tot = __shfl(incl, 63, 64);
+    run_g += tot & 0xffffu;
+    run_e += tot >> 16;
+  }
+  // padding of the ordering network / rank loop: composite 0 sorts last and is never emitted
+  int kpad;
+  if (k <= TK_RANK_MAX) kpad = (k + 3) & ~3;
+  else { kpad = 1; while (kpad < k) kpad <<= 1; }
+  for (int i = k + tid; i < kpad; i += TK_THREADS) sel[i] = 0;
+  __syncthreads();
+
+  int32_t* out = p.idx_out + (int64_t)row * p.idx_stride;
+  if (k <= TK_RANK_MAX) {
+    // rank by counting: composites are unique, so ranks form a permutation of 0..k-1
+    if (tid < k) {
+      const uint32_t mine = sel[tid];
+      int rank = 0;
+      const uint4* s4 = reinterpret_cast<const uint4*>(sel);
+      for (int j = 0; j < (kpad >> 2); ++j) {
+        const uint4 c = s4[j];   // same address for every lane: LDS broadcast
+        rank += (c.x > mine) + (c.y > mine) + (c.z > mine) + (c.w > mine);
+      }
+      out[rank] = (int32_t)(0xffffu - (mine & 0xffffu));
+    }
+  } else {
+    // bitonic network, descending
+    for (int size = 2; size <= kpad; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < (kpad >> 1); t += TK_THREADS) {
+          const int a = 2 * t - (t & (stride - 1));
+          const int b = a + stride;
+          const bool desc = (a & size) == 0;
+          const uint32_t va = sel[a], vb = sel[b];
+          if ((va < vb) == desc) { sel[a] = vb; sel[b] = va; }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < k; i += TK_THREADS) out[i] = (int32_t)(0xffffu - (sel[i] & 0xffffu));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sort_rows_kernel: full stable descending sort of one score row (L <= 32768) in LDS.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* sel = reinterpret_cast<uint32_t*>(smem);
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x;
+  const int L = p.L, n = p.n;
+  const uint16_t* src = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)row * p.scores_stride;
+  for (int i = tid; i < n; i += TK_THREADS)
+    sel[i] = (i < L) ? ((order_key<T>(src[i]) << 16) | (0xffffu - (uint32_t)i)) : 0u;
+  __syncthreads();
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (n >> 1); t += TK_THREADS) {
+        const int a = 2 * t - (t & (stride - 1));
+        const int b = a + stride;
+        const bool desc = (a & size) == 0;
+        const uint32_t va = sel[a], vb = sel[b];
+        if ((va < vb) == desc) { sel[a] = vb; sel[b] = va; }
+      }
+      __syncthreads();
+    }
+  }
+  int32_t* oi = p.sorted_idx + (int64_t)row * L;
+  uint16_t* ov = p.sorted_val ? reinterpret_cast<uint16_t*>(p.sorted_val) + (int64_t)row * L : nullptr;
+  for (int i = tid; i < L; i += TK_THREADS) {
+    const int idx = (int)(0xffffu - (sel[i] & 0xffffu));
+    oi[i] = idx;
+    if (ov) ov[i] = src[idx];
+  }
+}
+
+template __global__ void topk_kernel<BF16>(TopkParams);
+template __global__ void topk_kernel<F16>(TopkParams);
+template __global__ void sort_rows_kernel<BF16>(SortParams);
+template __global__ void sort_rows_kernel<F16>(SortParams);
+
+hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st) {
+  auto fn = dtype == 0 ? topk_kernel<BF16> : topk_kernel<F16>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(rows), dim3(TK_THREADS), lds, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st) {
+  auto fn = dtype == 0 ? sort_rows_kernel<BF16> : sort_rows_kernel<F16>;
+  const size_t lds = (size_t)p.n * 4;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(rows), dim3(TK_THREADS), lds, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace pkv

@@ -1,0 +1,50 @@
+"""Head-sharded multi-GPU wrapper (one process per GPU, torch.distributed; backend "nccl" is RCCL over
+xGMI on ROCm, "gloo" on CPU for tests).
+
+The path shards by attention head: every (batch, head) row is independent from score to gather
+(reference pyramidkv_utils.py:334-346 operate along dim -1 / 2 only), and the per-layer k depends on
+the layer only, so all ranks select the same count.  Rank r owns heads [r*H/N, (r+1)*H/N) - with
+Llama-3-8B / Mistral-7B (8 KV heads) and N=8 that is exactly one KV head per GPU.  There is ONE
+exchange step per layer: an all-gather of the selected int32 indices (KBs; latency-bound, nowhere
+near the 7 x ~153 GB/s xGMI links).  Compacted K/V stay head-sharded, as tensor-parallel attention
+consumes them.  The reference has no distributed code at all.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_heads(num_heads: int, rank: int, world: int) -> Tuple[int, int]:
+    if num_heads % world:
+        raise ValueError(f"num_heads={num_heads} is not divisible by world_size={world}")
+    per = num_heads // world
+    return rank * per, (rank + 1) * per
+
+
+def allgather_indices(idx_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """idx_local int32 [B, H/N, k] on every rank -> int32 [B, H, k] on every rank (head-major order =
+    rank order).  One collective."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return idx_local
+    B, Hl, k = idx_local.shape
+    out = torch.empty(world, B, Hl, k, dtype=idx_local.dtype, device=idx_local.device)
+    dist.all_gather_into_tensor(out, idx_local.contiguous(), group=group)
+    return out.permute(1, 0, 2, 3).reshape(B, world * Hl, k)
+
+
+class HeadShardedCluster:
+    """Wraps a SnapKV/PyramidKV/H2O-style cluster: ``update_kv`` runs the local heads through the HIP
+    path and all-gathers the selected indices.  ``select_fn(q,k,v) -> (kc, vc, idx)`` is the local
+    compress returning indices (``ops.compress(..., return_indices=True)``)."""
+
+    def __init__(self, select_fn, group: Optional[dist.ProcessGroup] = None):
+        self.select_fn = select_fn
+        self.group = group
+
+    def update_kv(self, key_states, query_states, value_states):
+        kc, vc, idx = self.select_fn(query_states, key_states, value_states)
+        return kc, vc, allgather_indices(idx, self.group)

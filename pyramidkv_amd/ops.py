@@ -1,0 +1,249 @@
+"""Stage-level host wrappers over the C ABI (include/pkv.h).
+
+PyTorch is used for device memory and the current stream only; all arithmetic happens in libpkv's
+HIP kernels.  Every function raises if the tensors are not on a HIP device - there is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _native as N
+
+_WS: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _require_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pyramidkv_amd runs on MI355X (HIP) tensors only; got a CPU tensor. "
+                               "There is no CPU fallback - use the reference (or oracle/) on CPU.")
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    """[B,H,S,D] with D contiguous and 16-byte aligned rows; anything else is materialised."""
+    if t.stride(-1) != 1 or any(s % 8 for s in t.stride()[:-1]) or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def make_desc(q: Optional[torch.Tensor], k: torch.Tensor, v: Optional[torch.Tensor], window: int,
+              pooling=None, kernel_size: int = 1, reduce: str = "sum", scale_mode: str = "div",
+              topk: int = 0, kv_group: int = 1, num_heads: Optional[int] = None) -> N.PkvDesc:
+    B, Hk, S, D = k.shape
+    H = num_heads if num_heads is not None else (q.shape[1] if q is not None else Hk * kv_group)
+    d = N.PkvDesc()
+    d.dtype = N.dtype_code(k.dtype)
+    d.B, d.H, d.S, d.D = B, H, S, D
+    d.kv_group = kv_group
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v)):
+        arr = getattr(d, name)
+        st = t.stride()[:3] if t is not None else k.stride()[:3]
+        for i in range(3):
+            arr[i] = st[i]
+    d.window = window
+    d.pool_kind = N.POOL[pooling]
+    d.pool_kernel = kernel_size if pooling not in (None, "none") else 1
+    d.reduce = N.REDUCE[reduce]
+    d.scale_mode = N.SCALE[scale_mode]
+    d.topk = topk
+    return d
+
+
+def _lp(L: int) -> int:
+    return (L + 7) // 8 * 8
+
+
+def score_window(q, k, window: int, pooling=None, kernel_size: int = 1, reduce: str = "sum",
+                 scale_mode: str = "div", kv_group: int = 1) -> torch.Tensor:
+    """pyramidkv_utils.py:317-333.  Returns [B,H,S-w] (a view of a [B,H,Lp] buffer)."""
+    _require_gpu(q, k)
+    q, k = _rowmajor(q), _rowmajor(k)
+    B, H, S, _ = q.shape
+    L = S - window
+    with torch.cuda.device(k.device):
+        d = make_desc(q, k, None, window, pooling, kernel_size, reduce, scale_mode, 0, kv_group)
+        nb = N.lib.pkv_workspace_bytes(d)
+        ws = workspace(nb, k.device)
+        out = torch.empty(B, H, _lp(L), dtype=k.dtype, device=k.device)
+        N.check(N.lib.pkv_score_window(d, q.data_ptr(), k.data_ptr(), out.data_ptr(), _lp(L), ws.data_ptr(),
+                                       ws.numel(), N.stream_ptr()), "pkv_score_window")
+    return out[..., :L]
+
+
+def score_h2o(q, k, window: int, scale_mode: str = "div", kv_group: int = 1) -> torch.Tensor:
+    """pyramidkv_utils.py:544-554."""
+    _require_gpu(q, k)
+    q, k = _rowmajor(q), _rowmajor(k)
+    B, H, S, _ = q.shape
+    L = S - window
+    with torch.cuda.device(k.device):
+        d = make_desc(q, k, None, window, None, 1, "sum", scale_mode, 0, kv_group)
+        ws = workspace(N.lib.pkv_workspace_bytes(d), k.device)
+        out = torch.empty(B, H, _lp(L), dtype=k.dtype, device=k.device)
+        N.check(N.lib.pkv_score_h2o(d, q.data_ptr(), k.data_ptr(), out.data_ptr(), _lp(L), ws.data_ptr(),
+                                    ws.numel(), N.stream_ptr()), "pkv_score_h2o")
+    return out[..., :L]
+
+
+def topk(scores: torch.Tensor, k: int) -> torch.Tensor:
+    """pyramidkv_utils.py:334.  scores [..., L] (16-bit) -> int32 [..., k], (value desc, index asc)."""
+    _require_gpu(scores)
+    if scores.stride(-1) != 1:
+        scores = scores.contiguous()
+    L = scores.shape[-1]
+    lead = scores.shape[:-1]
+    rows = int(math.prod(lead)) if len(lead) else 1
+    if scores.dim() > 1:
+        stride = scores.stride(-2)
+        flat_ok = all(scores.stride(i) == scores.stride(i + 1) * scores.shape[i + 1] for i in range(scores.dim() - 2))
+        if not flat_ok:
+            scores = scores.contiguous()
+            stride = L
+    else:
+        stride = L
+    out = torch.empty(*lead, k, dtype=torch.int32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        N.check(N.lib.pkv_topk(N.dtype_code(scores.dtype), rows, L, k, scores.data_ptr(), stride, None,
+                               out.data_ptr(), k, N.stream_ptr()), "pkv_topk")
+    return out
+
+
+def gather_compact(k, v, idx: torch.Tensor, window: int, kv_group: int = 1):
+    """pyramidkv_utils.py:335,341-346.  idx int32 [B,H,n] -> (K_c, V_c) [B,H,n+w,D]."""
+    _require_gpu(k, v, idx)
+    k, v = _rowmajor(k), _rowmajor(v)
+    B, H, n = idx.shape
+    idx = idx.to(torch.int32).contiguous()
+    D = k.shape[-1]
+    with torch.cuda.device(k.device):
+        d = make_desc(None, k, v, window, topk=n, kv_group=kv_group, num_heads=H)
+        ko = torch.empty(B, H, n + window, D, dtype=k.dtype, device=k.device)
+        vo = torch.empty_like(ko)
+        N.check(N.lib.pkv_gather_compact(d, k.data_ptr(), v.data_ptr(), idx.data_ptr(), n, ko.data_ptr(),
+                                         vo.data_ptr(), N.stream_ptr()), "pkv_gather_compact")
+    return ko, vo
+
+
+def gather_streaming(k, v, n_sink: int, window: int):
+    """pyramidkv_utils.py:607-620."""
+    _require_gpu(k, v)
+    k, v = _rowmajor(k), _rowmajor(v)
+    B, H, S, D = k.shape
+    with torch.cuda.device(k.device):
+        d = make_desc(None, k, v, window, topk=n_sink, num_heads=H)
+        ko = torch.empty(B, H, n_sink + window, D, dtype=k.dtype, device=k.device)
+        vo = torch.empty_like(ko)
+        N.check(N.lib.pkv_gather_streaming(d, k.data_ptr(), v.data_ptr(), ko.data_ptr(), vo.data_ptr(),
+                                           N.stream_ptr()), "pkv_gather_streaming")
+    return ko, vo
+
+
+def compress(q, k, v, window: int, topk_k: int, pooling, kernel_size: int, scale_mode: str = "div",
+             kv_group: int = 1, h2o: bool = False, return_indices: bool = False):
+    """Fused score -> top-k -> gather (pyramidkv_utils.py:317-346 / :544-575): one C call."""
+    _require_gpu(q, k, v)
+    q, k, v = _rowmajor(q), _rowmajor(k), _rowmajor(v)
+    B, H, S, D = q.shape
+    with torch.cuda.device(k.device):
+        d = make_desc(q, k, v, window, None if h2o else pooling, kernel_size, "sum", scale_mode, topk_k, kv_group)
+        ws = workspace(N.lib.pkv_workspace_bytes(d), k.device)
+        ko = torch.empty(B, H, topk_k + window, D, dtype=k.dtype, device=k.device)
+        vo = torch.empty_like(ko)
+        idx = torch.empty(B, H, topk_k, dtype=torch.int32, device=k.device) if return_indices else None
+        fn = N.lib.pkv_compress_h2o if h2o else N.lib.pkv_compress
+        N.check(fn(d, q.data_ptr(), k.data_ptr(), v.data_ptr(), ko.data_ptr(), vo.data_ptr(),
+                   idx.data_ptr() if idx is not None else None, ws.data_ptr(), ws.numel(), N.stream_ptr()),
+                "pkv_compress")
+    return (ko, vo, idx) if return_indices else (ko, vo)
+
+
+def sort_rows(scores: torch.Tensor, want_values: bool = True):
+    """pyramidkv_utils.py:706.  scores [rows, L] -> (sorted_idx int32 [rows,L], sorted_val or None)."""
+    _require_gpu(scores)
+    assert scores.dim() == 2
+    if scores.stride(-1) != 1:
+        scores = scores.contiguous()
+    rows, L = scores.shape
+    si = torch.empty(rows, L, dtype=torch.int32, device=scores.device)
+    sv = torch.empty(rows, L, dtype=scores.dtype, device=scores.device) if want_values else None
+    with torch.cuda.device(scores.device):
+        N.check(N.lib.pkv_sort_rows(N.dtype_code(scores.dtype), rows, L, scores.data_ptr(), scores.stride(0),
+                                    si.data_ptr(), sv.data_ptr() if sv is not None else None, N.stream_ptr()),
+                "pkv_sort_rows")
+    return si, sv
+
+
+def ada_budget(sorted_val: torch.Tensor, base_capacity: int, floor_ratio: float, normalize: bool) -> torch.Tensor:
+    """pyramidkv_utils.py:709-719.  sorted_val [H,L] descending -> int32 head_capacity [H]."""
+    _require_gpu(sorted_val)
+    sorted_val = sorted_val.contiguous()
+    H, L = sorted_val.shape
+    cap = torch.empty(H, dtype=torch.int32, device=sorted_val.device)
+    nb = 1024 + 2 * H * 256 * 4
+    ws = torch.empty(nb, dtype=torch.uint8, device=sorted_val.device)
+    with torch.cuda.device(sorted_val.device):
+        N.check(N.lib.pkv_ada_budget(N.dtype_code(sorted_val.dtype), H, L, sorted_val.data_ptr(), base_capacity,
+                                     float(floor_ratio), 1 if normalize else 0, cap.data_ptr(), ws.data_ptr(), nb,
+                                     N.stream_ptr()), "pkv_ada_budget")
+    return cap
+
+
+def ada_metadata(head_capacity: torch.Tensor, window: int):
+    """pyramidkv_utils.py:682-691.  -> (head_lens int32 [H], cu_klen int32 [H+1])."""
+    _require_gpu(head_capacity)
+    H = head_capacity.numel()
+    head_lens = torch.empty(H, dtype=torch.int32, device=head_capacity.device)
+    cu = torch.empty(H + 1, dtype=torch.int32, device=head_capacity.device)
+    with torch.cuda.device(head_capacity.device):
+        N.check(N.lib.pkv_ada_metadata(H, window, head_capacity.data_ptr(), head_lens.data_ptr(), cu.data_ptr(),
+                                       N.stream_ptr()), "pkv_ada_metadata")
+    return head_lens, cu
+
+
+def gather_flat(k, v, sorted_idx: torch.Tensor, head_capacity: torch.Tensor, cu_klen: torch.Tensor,
+                window: int, total_rows: int, max_cap: int = 0, kv_group: int = 1):
+    """pyramidkv_utils.py:733-757.  -> flat (K, V) [total_rows, D]."""
+    _require_gpu(k, v, sorted_idx)
+    k, v = _rowmajor(k), _rowmajor(v)
+    H = sorted_idx.shape[0]
+    D = k.shape[-1]
+    with torch.cuda.device(k.device):
+        d = make_desc(None, k, v, window, topk=max_cap, kv_group=kv_group, num_heads=H)
+        ko = torch.empty(total_rows, D, dtype=k.dtype, device=k.device)
+        vo = torch.empty_like(ko)
+        N.check(N.lib.pkv_gather_flat(d, k.data_ptr(), v.data_ptr(), sorted_idx.data_ptr(), sorted_idx.stride(0),
+                                      head_capacity.data_ptr(), cu_klen.data_ptr(), ko.data_ptr(), vo.data_ptr(),
+                                      N.stream_ptr()), "pkv_gather_flat")
+    return ko, vo
+
+
+def update_flatten_view(cache: torch.Tensor, state: torch.Tensor, head_lens: torch.Tensor,
+                        cu_klen: torch.Tensor) -> torch.Tensor:
+    """Replacement of tiny_api_cuda.update_flatten_view (csrc/csrc/cuda_api.cu:55-85)."""
+    _require_gpu(cache, state, head_lens, cu_klen)
+    if head_lens.dtype != torch.int32:
+        raise ValueError("expected headlens to be int32")          # cuda_api.cu:56
+    if cu_klen.dtype != torch.int32:
+        raise ValueError("expected cu_dst_pos to be int32")        # cuda_api.cu:57
+    cache, state = cache.contiguous(), state.contiguous()
+    H = head_lens.numel()
+    dim = cache.shape[1]
+    out = torch.empty(cache.shape[0] + H, dim, dtype=cache.dtype, device=cache.device)
+    with torch.cuda.device(cache.device):
+        N.check(N.lib.pkv_update_flatten_view(N.dtype_code(cache.dtype), H, dim, cache.data_ptr(), state.data_ptr(),
+                                              head_lens.data_ptr(), cu_klen.data_ptr(), out.data_ptr(),
+                                              N.stream_ptr()), "pkv_update_flatten_view")
+    return out

@@ -1,0 +1,385 @@
+"""Drop-in replacement for the reference's ``pyramidkv/pyramidkv_utils.py`` KV-cluster classes.
+
+Same class names, constructor keywords, ``update_kv`` signatures, return conventions and ``init_*``
+factories as the reference (file:line cited per symbol), so the reference's patched attention
+forwards (``llama_model.py`` / ``mistral_model.py``) work unchanged when this module is swapped in
+for ``pyramidkv.pyramidkv_utils``.  The body of every ``update_kv`` is one or a few calls into
+libpkv's HIP kernels through the C ABI (``include/pkv.h``); nothing is computed in PyTorch.
+
+Differences from the reference, all deliberate:
+  * no per-call ``print`` (pyramidkv_utils.py:217,312,539,601 write to stdout on every layer);
+  * ``merge`` (LOOK-M pivot merge, :119-170) is out of scope: a non-None ``merge`` raises;
+  * top-k tie order is pinned to (value desc, index asc) - see DESIGN.md;
+  * tensors must live on a HIP device (no CPU path).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from . import config as _cfg
+
+
+def _check_merge(merge):
+    if merge is not None:
+        raise NotImplementedError("merge (LOOK-M pivot merge, reference pyramidkv_utils.py:119-170) is out of scope "
+                                  "of pyramidkv_amd; pass merge=None")
+
+
+def _kv_group(num_key_value_groups, num_heads) -> int:
+    """GQA de-duplication is opt-in: the reference hands over K/V already expanded by repeat_kv
+    (llama_model.py:158-159) and ignores num_key_value_groups.  With config.gqa_dedup the kernels read
+    only the first head of every group of the (materialised) expanded tensor."""
+    g = int(num_key_value_groups or 1)
+    if _cfg.gqa_dedup and g > 1 and num_heads % g == 0:
+        return g
+    return 1
+
+
+def _dedup_view(t: torch.Tensor, g: int) -> torch.Tensor:
+    return t if g == 1 else t[:, ::g]
+
+
+class _WindowPolicy:
+    """Shared body of SnapKV / PyramidKV / H2O: score -> top-k -> gather in one C call."""
+
+    window_size: int
+    kernel_size: int
+    pooling: str
+
+    def _compress(self, key_states, query_states, value_states, k, num_key_value_groups, h2o=False):
+        g = _kv_group(num_key_value_groups, query_states.shape[1])
+        return ops.compress(query_states, _dedup_view(key_states, g), _dedup_view(value_states, g),
+                            self.window_size, k, self.pooling, self.kernel_size,
+                            scale_mode=_cfg.scale_mode, kv_group=g, h2o=h2o)
+
+
+class PyramidKVCluster(_WindowPolicy):
+    """reference pyramidkv_utils.py:173-283."""
+
+    def __init__(self, num_hidden_layers=32, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5,
+                 pooling='avgpool', beta=20, num_layers=80, layer_idx=None, merge=None):
+        self.layer_idx = layer_idx
+        self.num_hidden_layers = num_hidden_layers
+        self.steps = -1
+        self.beta = beta
+        self.window_size = window_size
+        self.max_capacity_prompt = max_capacity_prompt
+        assert self.max_capacity_prompt - self.window_size > 0                      # :184
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.merge = merge
+
+    def reset(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None):
+        self.window_size = window_size
+        self.max_capacity_prompt = max_capacity_prompt
+        assert self.max_capacity_prompt - self.window_size > 0
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.merge = merge
+
+    def layer_budget(self, q_len: int):
+        """Integer budget arithmetic of :205-215 and the branch thresholds of :218,:220,:252."""
+        min_num = (self.max_capacity_prompt - self.window_size) // self.beta
+        max_num = (self.max_capacity_prompt - self.window_size) * 2 - min_num
+        if max_num >= q_len - self.window_size:
+            max_num = q_len - self.window_size
+            min_num = (self.max_capacity_prompt - self.window_size) * 2 - max_num
+        steps = (max_num - min_num) // (self.num_hidden_layers - 1)
+        max_capacity_prompt = max_num - self.layer_idx * steps
+        if q_len < self.max_capacity_prompt:
+            return "passthrough", 0
+        if q_len < (self.max_capacity_prompt - self.window_size) * 2:
+            return "snap", self.max_capacity_prompt - self.window_size
+        return "pyramid", max_capacity_prompt
+
+    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
+        assert key_states.shape[-2] == query_states.shape[-2]                       # :200
+        q_len = query_states.shape[-2]
+        branch, k = self.layer_budget(q_len)
+        if branch == "passthrough":
+            return key_states, value_states                                          # :219 (same objects)
+        if self.pooling not in ('avgpool', 'maxpool'):
+            raise ValueError('Pooling method not supported')                         # :237
+        _check_merge(self.merge)
+        return self._compress(key_states, query_states, value_states, k, num_key_value_groups)
+
+
+class SnapKVCluster(_WindowPolicy):
+    """reference pyramidkv_utils.py:285-347."""
+
+    def __init__(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None,
+                 recent_size=32, ratio=0.4):
+        self.window_size = window_size
+        self.max_capacity_prompt = max_capacity_prompt
+        assert self.max_capacity_prompt - self.window_size > 0                      # :289
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.merge = merge
+        self.recent_size = recent_size
+        self.ratio = ratio
+
+    def reset(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None):
+        self.window_size = window_size
+        self.max_capacity_prompt = max_capacity_prompt
+        assert self.max_capacity_prompt - self.window_size > 0
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.merge = merge
+
+    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
+        assert key_states.shape[-2] == query_states.shape[-2]                       # :309
+        q_len = query_states.shape[-2]
+        if q_len < self.max_capacity_prompt:                                        # :314
+            return key_states, value_states
+        if self.pooling not in ('avgpool', 'maxpool'):
+            raise ValueError('Pooling method not supported')                         # :333
+        _check_merge(self.merge)
+        return self._compress(key_states, query_states, value_states,
+                              self.max_capacity_prompt - self.window_size, num_key_value_groups)
+
+
+class H2OKVCluster(_WindowPolicy):
+    """reference pyramidkv_utils.py:516-575."""
+
+    def __init__(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None):
+        self.window_size = window_size
+        self.max_capacity_prompt = max_capacity_prompt
+        assert self.max_capacity_prompt - self.window_size > 0
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.merge = merge
+
+    reset = __init__
+
+    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
+        assert key_states.shape[-2] == query_states.shape[-2]                       # :536
+        q_len = query_states.shape[-2]
+        if q_len < self.max_capacity_prompt:                                        # :541
+            return key_states, value_states
+        _check_merge(self.merge)
+        return self._compress(key_states, query_states, value_states,
+                              self.max_capacity_prompt - self.window_size, num_key_value_groups, h2o=True)
+
+
+class StreamingLLMKVCluster:
+    """reference pyramidkv_utils.py:578-620: attention sinks 0..cap-w-1 + the last w tokens."""
+
+    def __init__(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None):
+        self.window_size = window_size
+        self.max_capacity_prompt = max_capacity_prompt
+        assert self.max_capacity_prompt - self.window_size > 0
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.merge = merge
+
+    reset = __init__
+
+    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
+        assert key_states.shape[-2] == query_states.shape[-2]                       # :598
+        q_len = query_states.shape[-2]
+        if q_len < self.max_capacity_prompt:                                        # :603
+            return key_states, value_states
+        _check_merge(self.merge)
+        return ops.gather_streaming(key_states, value_states, self.max_capacity_prompt - self.window_size,
+                                    self.window_size)
+
+
+class _FlatPolicy:
+    """Shared var-len metadata of AdaKV / HeadKV (reference :682-698)."""
+
+    def _init_state(self):
+        self.head_lens = None
+        self.max_seqlen_k = 0
+        self.klen_sum = 0
+        self.cu_klen = 0
+        self.cu_offset = None
+        self.cu_headlens = None
+
+    def _init_metadata(self, num_heads, head_lens, cu_klen, klen_sum, max_seqlen_k, device):
+        self.head_lens = head_lens                                                   # int32 [H]          :684
+        self.klen_sum = klen_sum                                                     #                    :685
+        self.max_seqlen_k = max_seqlen_k                                             #                    :686
+        self.cu_headlens = cu_klen[1:].clone()                                       # inclusive prefix   :687
+        self.cu_klen = cu_klen                                                       # int32 [H+1]        :689-691
+        self.layer_qlens = torch.ones(num_heads, dtype=torch.int32, device=device)   #                    :692
+        self.qlen_sum = num_heads
+        self.cu_qlen = torch.arange(0, num_heads + 1, dtype=torch.int32, device=device)   # :694-696
+        self.cu_offset = torch.arange(0, num_heads + 1, dtype=torch.int32, device=device)  # :697
+        self.cu_head_offset = torch.arange(1, num_heads + 1, dtype=torch.int32, device=device)  # :698
+
+    def _scores(self, key_states, query_states):
+        """calcul_attn_sore (:647-672): mean over the window rows, then pooling."""
+        if self.pooling not in ('avgpool', 'maxpool'):
+            raise ValueError('Pooling method not supported')
+        return ops.score_window(query_states, key_states, self.window_size, self.pooling, self.kernel_size,
+                                reduce="mean", scale_mode=_cfg.scale_mode)
+
+    def _passthrough(self, key_states, value_states, num_heads, q_len, head_dim):
+        dev = key_states.device
+        head_lens = torch.full((num_heads,), q_len, dtype=torch.int32, device=dev)
+        cu = torch.arange(0, num_heads + 1, dtype=torch.int32, device=dev) * q_len
+        self._init_metadata(num_heads, head_lens, cu, q_len * num_heads, q_len, dev)  # :701
+        return key_states.reshape(-1, head_dim), value_states.reshape(-1, head_dim)   # :703
+
+    def _flat_from_capacity(self, key_states, value_states, sorted_idx, cap_dev, num_heads):
+        head_lens, cu = ops.ada_metadata(cap_dev, self.window_size)
+        caps = cap_dev.tolist()          # host sync: the boundary exposes klen_sum/max_seqlen_k as ints (:685-686)
+        klen_sum = sum(caps) + num_heads * self.window_size
+        max_cap = max(caps)
+        kf, vf = ops.gather_flat(key_states, value_states, sorted_idx, cap_dev, cu, self.window_size, klen_sum,
+                                 max_cap=max_cap)
+        self._init_metadata(num_heads, head_lens, cu, klen_sum, max_cap + self.window_size, key_states.device)
+        self.head_capacity_last = caps
+        return kf, vf
+
+
+class AdaKVCluster(_FlatPolicy):
+    """reference pyramidkv_utils.py:622-757 (adapted there from FFY0/AdaKV)."""
+
+    def __init__(self, window_size=32, kernel_size=7, pooling='maxpool', max_capacity_prompt=None, floor=None,
+                 normalize=None, layer_idx=None, num_hidden_layers=None):
+        self.window_size = window_size
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.base_capacity = max_capacity_prompt - window_size                       # :630
+        self.floor_ratio = floor
+        self.floor_capacity = int(self.base_capacity * self.floor_ratio)             # :632
+        self.adaptive_capacity = self.base_capacity - self.floor_capacity
+        self.num_hidden_layers = num_hidden_layers
+        self.normalize = normalize
+        self.layer_idx = layer_idx
+        self._init_state()
+
+    def update_kv(self, key_states, query_states, value_states):
+        bsz, num_heads, q_len, head_dim = query_states.shape
+        L = q_len - self.window_size
+        if self.base_capacity > L:                                                   # :700
+            return self._passthrough(key_states, value_states, num_heads, q_len, head_dim)
+        assert bsz == 1                                                              # :724
+        attn_score = self._scores(key_states, query_states)                          # [1,H,L]
+        sorted_idx, sorted_val = ops.sort_rows(attn_score[0])                        # :706
+        cap = ops.ada_budget(sorted_val, self.base_capacity, self.floor_ratio, bool(self.normalize))  # :709-719
+        return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads)
+
+
+class HeadKVCluster(_FlatPolicy):
+    """reference pyramidkv_utils.py:760-878: AdaKV gather with precomputed head_capacity[layer][head]."""
+
+    def __init__(self, window_size=32, kernel_size=7, pooling='maxpool', max_capacity_prompt=None, layer_idx=None,
+                 num_hidden_layers=None, head_capacity=None):
+        self.window_size = window_size
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.base_capacity = max_capacity_prompt - window_size
+        self.head_adaptive_capacity = head_capacity
+        self.num_hidden_layers = num_hidden_layers
+        self.layer_idx = layer_idx
+        self._init_state()
+
+    def update_kv(self, key_states, query_states, value_states):
+        bsz, num_heads, q_len, head_dim = query_states.shape
+        L = q_len - self.window_size
+        if self.base_capacity > L:                                                   # :834
+            return self._passthrough(key_states, value_states, num_heads, q_len, head_dim)
+        assert bsz == 1                                                              # :845
+        attn_score = self._scores(key_states, query_states)
+        sorted_idx, _ = ops.sort_rows(attn_score[0], want_values=False)              # :840
+        caps = [min(int(self.head_adaptive_capacity[self.layer_idx][h]), L) for h in range(num_heads)]  # :855 slice
+        cap = torch.tensor(caps, dtype=torch.int32, device=key_states.device)
+        return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads)
+
+
+# ------------------------------------------------------------------------------------------------
+# init_* factories: the plugin seam read by the patched attention forwards (reference :880-1085)
+# ------------------------------------------------------------------------------------------------
+def _default(config, name, value):
+    if not hasattr(config, name):
+        setattr(config, name, value)
+
+
+def init_pyramidkv(self, num_hidden_layers):
+    """reference :880-902 (cluster rebuilt on every call, as there)."""
+    if not hasattr(self, "kv_cluster"):
+        _default(self.config, 'window_size', 32)
+        _default(self.config, 'max_capacity_prompt', 2048)
+        _default(self.config, 'kernel_size', 5)
+        _default(self.config, 'pooling', 'avgpool')
+        _default(self.config, 'merge', None)
+    self.kv_cluster = PyramidKVCluster(
+        num_hidden_layers=num_hidden_layers, layer_idx=self.layer_idx, window_size=self.config.window_size,
+        max_capacity_prompt=self.config.max_capacity_prompt, kernel_size=self.config.kernel_size,
+        pooling=self.config.pooling, merge=self.config.merge)
+
+
+def init_snapkv(self):
+    """reference :904-924."""
+    if not hasattr(self, "kv_cluster"):
+        _default(self.config, 'window_size', 32)
+        _default(self.config, 'max_capacity_prompt', 4096)
+        _default(self.config, 'kernel_size', 5)
+        _default(self.config, 'pooling', 'avgpool')
+        _default(self.config, 'merge', None)
+    self.kv_cluster = SnapKVCluster(
+        window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
+        kernel_size=self.config.kernel_size, pooling=self.config.pooling, merge=self.config.merge)
+
+
+def init_H2O(self):
+    """reference :990-1009."""
+    if not hasattr(self, "kv_cluster"):
+        _default(self.config, 'window_size', 32)
+        _default(self.config, 'max_capacity_prompt', 2048)
+        _default(self.config, 'kernel_size', 5)
+        _default(self.config, 'pooling', 'avgpool')
+        _default(self.config, 'merge', None)
+    self.kv_cluster = H2OKVCluster(
+        window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
+        kernel_size=self.config.kernel_size, pooling=self.config.pooling, merge=self.config.merge)
+
+
+def init_StreamingLLM(self):
+    """reference :1011-1031."""
+    if not hasattr(self, "kv_cluster"):
+        _default(self.config, 'window_size', 32)
+        _default(self.config, 'max_capacity_prompt', 2048)
+        _default(self.config, 'kernel_size', 5)
+        _default(self.config, 'pooling', 'avgpool')
+        _default(self.config, 'merge', None)
+    self.kv_cluster = StreamingLLMKVCluster(
+        window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
+        kernel_size=self.config.kernel_size, pooling=self.config.pooling, merge=self.config.merge)
+
+
+def init_adakv(self):
+    """reference :1033-1059 (built once; reads config.floor like the reference does at :1057)."""
+    if not hasattr(self, "kv_cluster"):
+        _default(self.config, 'window_size', 32)
+        _default(self.config, 'max_capacity_prompt', 2048)
+        _default(self.config, 'kernel_size', 5)
+        _default(self.config, 'pooling', 'maxpool')
+        _default(self.config, 'floor_ratio', 0.2)
+        _default(self.config, 'normalize', True)
+    if not hasattr(self, "kv_cluster"):
+        self.kv_cluster = AdaKVCluster(
+            num_hidden_layers=self.config.num_hidden_layers, layer_idx=self.layer_idx,
+            window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
+            kernel_size=self.config.kernel_size, pooling=self.config.pooling, floor=self.config.floor,
+            normalize=self.config.normalize)
+
+
+def init_headkv(self):
+    """reference :1062-1085."""
+    if not hasattr(self, "kv_cluster"):
+        _default(self.config, 'window_size', 32)
+        _default(self.config, 'max_capacity_prompt', 2048)
+        _default(self.config, 'kernel_size', 5)
+        _default(self.config, 'pooling', 'maxpool')
+        if not hasattr(self.config, 'head_capacity'):
+            raise ValueError("Must have head_capacity")                              # :1073
+    if not hasattr(self, "kv_cluster"):
+        self.kv_cluster = HeadKVCluster(
+            num_hidden_layers=self.config.num_hidden_layers, layer_idx=self.layer_idx,
+            window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
+            kernel_size=self.config.kernel_size, pooling=self.config.pooling,
+            head_capacity=self.config.head_capacity)

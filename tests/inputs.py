@@ -23,18 +23,19 @@ def make_qkv(B, H, S, D, dtype, kind, seed, device="cpu"):
     elif kind == "lattice":
         q, k, v = (torch.randint(-4, 5, (B, H, S, D), generator=g).float() / 4 for _ in range(3))
     elif kind == "planted":
-        q = torch.randn(B, H, S, D, generator=g) * 0.25
-        k = torch.randn(B, H, S, D, generator=g) * 0.25
+        # tiny background + 64 heavy-hitter keys aligned with a direction u shared by the window
+        # queries; hitter logits are ~0.1 apart (>> 1 ulp of the score dtype after softmax)
+        q = torch.randn(B, H, S, D, generator=g) * 0.02
+        k = torch.randn(B, H, S, D, generator=g) * 0.02
         v = torch.randn(B, H, S, D, generator=g)
-        n_hit = max(8, min(512, S // 16))
+        n_hit = 64
         for b in range(B):
             for h in range(H):
-                pos = torch.randperm(S - 64, generator=g)[:n_hit] if S > 128 else torch.arange(0)
-                # direction shared by the window queries; hitters align with it at distinct strengths
+                pos = (torch.randperm((S - 128) // 16, generator=g)[:n_hit] * 16 + 8) if S >= 2048 else torch.arange(0)
                 u = torch.randn(D, generator=g)
                 u = u / u.norm()
                 q[b, h, -64:] += 6.0 * u
-                strength = torch.linspace(2.0, 9.0, len(pos))
+                strength = torch.linspace(2.0, 14.0, len(pos))
                 k[b, h, pos] += strength[:, None] * u
     else:
         raise ValueError(kind)

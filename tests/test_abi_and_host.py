@@ -1,0 +1,145 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/pkv.h declares; the host
+logic (budgets, pass-through, argument checking, error behaviour) mirrors the reference.  No compute
+kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from inputs import make_qkv
+from oracle import pkv_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def P():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(ROOT, "pyramidkv_amd", "libpkv.so")):
+        g.build()
+    import pyramidkv_amd
+    return pyramidkv_amd
+
+
+def test_header_symbols_exported(P):
+    hdr = open(os.path.join(ROOT, "include", "pkv.h")).read()
+    declared = set(re.findall(r"\b(pkv_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(os.path.join(ROOT, "pyramidkv_amd", "libpkv.so"))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/pkv.h but not exported by libpkv.so"
+    assert set(P._native.EXPORTED) == declared
+    assert lib.pkv_version() == 100
+
+
+def test_strerror_and_argument_validation_without_gpu(P):
+    N = P._native
+    assert N.lib.pkv_strerror(0) == b"ok"
+    d = N.PkvDesc()
+    d.dtype, d.B, d.H, d.S, d.D, d.kv_group, d.window, d.topk = 0, 1, 2, 64, 64, 1, 8, 4   # D != 128
+    assert N.lib.pkv_gather_streaming(d, 16, 16, 16, 16, None) == -2
+    d.D = 128
+    d.dtype = 7
+    assert N.lib.pkv_gather_streaming(d, 16, 16, 16, 16, None) == -1
+    d.dtype = 0
+    assert N.lib.pkv_gather_streaming(d, None, 16, 16, 16, None) == -7
+    for i in range(3):
+        d.k_stride[i] = d.v_stride[i] = d.q_stride[i] = 128
+    d.k_stride[2] = 130                                        # rows not 16-byte aligned
+    assert N.lib.pkv_gather_streaming(d, 16, 16, 16, 16, None) == -3
+    assert N.lib.pkv_topk(0, 1, 100000, 5, 16, 100000, None, 16, 5, None) == -5   # L beyond the LDS limit
+    assert N.lib.pkv_topk(0, 1, 100, 500, 16, 100, None, 16, 500, None) == -2     # k > L
+    assert N.lib.pkv_workspace_bytes(d) > 0
+    with pytest.raises(ValueError):
+        N.check(-2, "x")
+    with pytest.raises(N.PkvError):
+        N.check(-4, "x")
+
+
+def test_pyramid_budget_matches_oracle_grid(P):
+    for cap in (64, 96, 128, 256, 2048):
+        for w in (8, 32):
+            if cap - w <= 0:
+                continue
+            for S in (cap - 1, cap, cap + 1, 2 * (cap - w) - 1, 2 * (cap - w), 2 * (cap - w) + 3, 4096, 32768):
+                if S <= w:
+                    continue
+                for layer in (0, 1, 7, 31):
+                    cl = P.PyramidKVCluster(num_hidden_layers=32, layer_idx=layer, window_size=w,
+                                            max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+                    assert cl.layer_budget(S) == O.pyramid_budget(cap, w, 32, layer, S)
+
+
+def test_passthrough_returns_input_objects(P):
+    q, k, v = make_qkv(1, 2, 48, 128, "bf16", "gauss", 1)
+    for cl in (P.SnapKVCluster(window_size=8, max_capacity_prompt=64), P.H2OKVCluster(window_size=8, max_capacity_prompt=64),
+               P.StreamingLLMKVCluster(window_size=8, max_capacity_prompt=64),
+               P.PyramidKVCluster(num_hidden_layers=32, layer_idx=2, window_size=8, max_capacity_prompt=64)):
+        kc, vc = cl.update_kv(k, q, v, None, 4)
+        assert kc is k and vc is v                     # reference :219,:315,:542,:604
+
+
+def test_constructor_contract_and_errors(P):
+    with pytest.raises(AssertionError):
+        P.SnapKVCluster(window_size=64, max_capacity_prompt=64)          # reference :289
+    q, k, v = make_qkv(1, 2, 256, 128, "bf16", "gauss", 1)
+    cl = P.SnapKVCluster(window_size=8, max_capacity_prompt=64, pooling="medianpool")
+    with pytest.raises(ValueError, match="Pooling method not supported"):   # reference :333
+        cl.update_kv(k, q, v, None, 1)
+    cl = P.SnapKVCluster(window_size=8, max_capacity_prompt=64, pooling="maxpool", merge="pivot")
+    with pytest.raises(NotImplementedError):
+        cl.update_kv(k, q, v, None, 1)
+    cl = P.SnapKVCluster(window_size=8, max_capacity_prompt=64, pooling="maxpool")
+    with pytest.raises(AssertionError):
+        cl.update_kv(k[:, :, :100], q, v, None, 1)                        # reference :309
+    with pytest.raises(RuntimeError, match="no CPU fallback|HIP"):        # product path never runs on CPU
+        cl.update_kv(k, q, v, None, 1)
+
+
+def test_init_factories_default_and_rebuild(P):
+    class Cfg:
+        num_hidden_layers = 32
+
+    class Attn:
+        pass
+
+    a = Attn()
+    a.config, a.layer_idx = Cfg(), 5
+    P.init_pyramidkv(a, 32)
+    assert (a.config.window_size, a.config.max_capacity_prompt, a.config.kernel_size, a.config.pooling) == (32, 2048, 5, "avgpool")
+    first = a.kv_cluster
+    assert isinstance(first, P.PyramidKVCluster) and first.layer_idx == 5 and first.beta == 20
+    P.init_pyramidkv(a, 32)
+    assert a.kv_cluster is not first                   # rebuilt on every call, reference :894
+    b = Attn()
+    b.config, b.layer_idx = Cfg(), 0
+    P.init_snapkv(b)
+    assert b.config.max_capacity_prompt == 4096        # reference :909
+    c = Attn()
+    c.config, c.layer_idx = Cfg(), 0
+    c.config.floor = 0.2
+    P.init_adakv(c)
+    once = c.kv_cluster
+    P.init_adakv(c)
+    assert c.kv_cluster is once                        # built once, reference :1049
+    assert c.config.pooling == "maxpool" and c.config.normalize is True
+    d = Attn()
+    d.config, d.layer_idx = Cfg(), 0
+    with pytest.raises(ValueError, match="Must have head_capacity"):
+        P.init_headkv(d)
+    for init in (P.init_H2O, P.init_StreamingLLM):
+        e = Attn()
+        e.config, e.layer_idx = Cfg(), 0
+        init(e)
+        assert e.config.max_capacity_prompt == 2048 and e.config.window_size == 32
+
+
+def test_missing_extension_fails_loudly(tmp_path, monkeypatch):
+    import importlib
+    import pyramidkv_amd._native as N
+    monkeypatch.setattr(N, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU/PyTorch fallback"):
+        N._load()
+    importlib.reload(N)

@@ -1,0 +1,444 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the oracle, stage by stage and end to end.
+
+Bars (DESIGN.md "Parity"):
+  * top-k indices and gather-compaction: BIT-EXACT vs the oracle on the same scores / indices;
+  * scores: floating point; every element within 1 ulp of the model dtype, and the fraction of
+    elements that differ at all <= SCORE_MISMATCH_FRAC (the two sides evaluate exp/sum in different
+    orders; the reference itself differs CPU vs GPU at this level - SURVEY.md section 7 hard part 1c);
+  * end to end: indices == canonical top-k of the kernel's own scores (exact), K/V == exact gather of
+    those indices; on margin-checked "planted" inputs indices/K/V are bit-identical to the oracle.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from inputs import make_qkv, bits, from_bits
+from oracle import pkv_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCORE_MISMATCH_FRAC = 2e-3
+DEV = "cuda"
+REPORT = {}
+
+
+def _report(key, val):
+    REPORT[key] = val
+    out = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, default=str)
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyramidkv_amd
+    return pyramidkv_amd
+
+
+def ord16(t: torch.Tensor) -> np.ndarray:
+    """monotone integer image of a 16-bit float tensor (for ulp distances)."""
+    b = bits(t).astype(np.int32)
+    return np.where(b & 0x8000, -(b & 0x7FFF), b)
+
+
+def score_diff(a: torch.Tensor, b: torch.Tensor):
+    da = np.abs(ord16(a) - ord16(b))
+    return float((da > 0).mean()), int(da.max())
+
+
+# ----------------------------------------------------------------------------------------- gather
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,S,w,k", [(1, 4, 512, 8, 56), (2, 3, 4096, 32, 2016), (1, 32, 32768, 8, 120),
+                                       (1, 2, 1000, 5, 1), (1, 2, 300, 8, 292)])
+def test_gather_bit_exact(P, dt, B, H, S, w, k):
+    q, kk, v = make_qkv(B, H, S, 128, dt, "gauss", 7)
+    g = torch.Generator().manual_seed(3)
+    idx = torch.stack([torch.stack([torch.randperm(S - w, generator=g)[:k] for _ in range(H)]) for _ in range(B)])
+    kc_ref, vc_ref = O.gather_compact(kk, v, idx, w)
+    kc, vc = P.ops.gather_compact(kk.to(DEV), v.to(DEV), idx.to(DEV).int(), w)
+    assert torch.equal(kc.cpu(), kc_ref) and torch.equal(vc.cpu(), vc_ref)
+
+
+def test_gather_strided_views_and_gqa(P):
+    # V as a transposed view (n_rep == 1 in the reference, pyramidkv_utils.py:114-115) and un-expanded GQA K/V
+    B, Hkv, S, w, k, g = 2, 2, 1024, 8, 100, 4
+    gen = torch.Generator().manual_seed(5)
+    kv = torch.randn(B, S, Hkv, 128, generator=gen).to(torch.bfloat16)
+    vv = torch.randn(B, S, Hkv, 128, generator=gen).to(torch.bfloat16)
+    K, V = kv.transpose(1, 2), vv.transpose(1, 2)                    # [B,Hkv,S,D] strided views
+    idx = torch.stack([torch.stack([torch.randperm(S - w, generator=gen)[:k] for _ in range(Hkv * g)]) for _ in range(B)])
+    Kx = K[:, :, None].expand(B, Hkv, g, S, 128).reshape(B, Hkv * g, S, 128)
+    Vx = V[:, :, None].expand(B, Hkv, g, S, 128).reshape(B, Hkv * g, S, 128)
+    kc_ref, vc_ref = O.gather_compact(Kx, Vx, idx, w)
+    Kd, Vd = kv.to(DEV).transpose(1, 2), vv.to(DEV).transpose(1, 2)
+    assert not Kd.is_contiguous()
+    kc, vc = P.ops.gather_compact(Kd, Vd, idx.to(DEV).int(), w, kv_group=g)
+    assert torch.equal(kc.cpu(), kc_ref) and torch.equal(vc.cpu(), vc_ref)
+
+
+def test_streaming_exact(P):
+    q, k, v = make_qkv(2, 4, 2048, 128, "bf16", "gauss", 9)
+    cl = P.StreamingLLMKVCluster(window_size=124, max_capacity_prompt=128)
+    kc, vc = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV), None, 1)
+    kr, vr = O.streamingllm_update_kv(k, q, v, 124, 128)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+
+
+# ----------------------------------------------------------------------------------------- top-k
+def _topk_check(P, scores_cpu, k):
+    want = O.topk_canonical(scores_cpu, k)
+    got = P.ops.topk(scores_cpu.to(DEV), k).cpu().long()
+    assert torch.equal(got, want), f"k={k} L={scores_cpu.shape[-1]}"
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_topk_oracle_scores(P, dt):
+    """Scores produced by the oracle from Gaussian q/k with the runners' maxpool-7 (ties everywhere)."""
+    for S, w, ks in ((4096, 8, [1, 17, 120, 234, 1000, 1025, 2040]), (32768, 8, [17, 120, 234, 2040, 3978])):
+        q, k, _ = make_qkv(1, 4, S, 128, dt, "gauss", 21)
+        for pool, ksz in (("maxpool", 7), ("avgpool", 5), (None, 1)):
+            s = O.pool_scores(O.window_scores(q, k, w), pool, ksz)
+            for kk in ks:
+                _topk_check(P, s, kk)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_topk_adversarial(P, dt):
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(0)
+    L = 5003                                                 # not a multiple of 8: scalar tail path
+    cases = {
+        "all_equal": torch.full((2, L), 0.25),
+        "two_values": (torch.rand(2, L, generator=g) > 0.5).float() * 0.5 + 0.125,
+        "plateau_at_kth": torch.cat([torch.full((2, 50), 1.0), torch.full((2, 400), 0.5), torch.rand(2, L - 450, generator=g) * 0.4], 1),
+        "descending": torch.linspace(1, 0, L).repeat(2, 1),
+        "ascending": torch.linspace(0, 1, L).repeat(2, 1),
+        "signed_inf_zero": torch.cat([torch.randn(2, L - 6, generator=g), torch.tensor([[float("inf"), -float("inf"), 0.0, -0.0, 1e-7, -1e-7]] * 2)], 1),
+        "few_distinct": torch.randint(0, 4, (2, L), generator=g).float() / 8,
+    }
+    for name, s in cases.items():
+        s = s.to(tdt)
+        for k in (1, 7, 100, 449, 450, 451, 1024, 1025, 3000, L - 1, L):
+            _topk_check(P, s, k)
+    # NaN sorts as greatest (torch semantics)
+    s = torch.rand(1, 777, generator=g).to(tdt)
+    s[0, 5] = float("nan")
+    s[0, 700] = float("nan")
+    _topk_check(P, s, 10)
+
+
+def test_topk_small_and_strided(P):
+    g = torch.Generator().manual_seed(1)
+    for L in (1, 2, 7, 8, 9, 63, 64, 65, 511, 513):
+        s = torch.rand(3, L, generator=g).to(torch.bfloat16)
+        for k in {1, max(1, L // 2), L}:
+            _topk_check(P, s, k)
+    big = torch.rand(3, 5, 1000, generator=g).to(torch.float16)
+    view = big[:, :, :992]                                   # row stride 1000 != L
+    want = O.topk_canonical(view, 33)
+    got = P.ops.topk(big.to(DEV)[:, :, :992], 33).cpu().long()
+    assert torch.equal(got, want)
+
+
+def test_topk_vs_torch_device_topk(P):
+    """H1: the reference's own ``topk`` executed by PyTorch-ROCm on this GPU.
+    Value sequences must agree; exact index agreement is recorded (it is what 'bit-identical to the
+    reference run on this device' means)."""
+    res = {}
+    for dt in ("bf16", "fp16"):
+        q, k, _ = make_qkv(1, 8, 8192, 128, dt, "gauss", 33)
+        for pool, ksz in (("maxpool", 7), ("avgpool", 5), (None, 1)):
+            s = O.pool_scores(O.window_scores(q, k, 8), pool, ksz).to(DEV)
+            for kk in (17, 120, 2040):
+                mine = P.ops.topk(s, kk).long()
+                ref = s.topk(kk, dim=-1).indices
+                assert torch.equal(torch.gather(s, -1, mine), torch.gather(s, -1, ref))
+                res[f"{dt}/{pool}/{kk}"] = float((mine == ref).all(-1).float().mean())
+    _report("H1_topk_rows_identical_to_torch_rocm_topk", res)
+
+
+# ----------------------------------------------------------------------------------------- scores
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", ["gauss", "lattice"])
+@pytest.mark.parametrize("B,H,S,w,pool,ks,red", [
+    (1, 4, 512, 8, "maxpool", 7, "sum"), (2, 2, 1000, 32, "avgpool", 5, "sum"), (1, 2, 4099, 8, None, 1, "sum"),
+    (1, 4, 2048, 8, "maxpool", 7, "mean"), (1, 2, 300, 64, "avgpool", 5, "mean"), (1, 2, 257, 1, "maxpool", 3, "sum"),
+])
+def test_window_scores(P, dt, kind, B, H, S, w, pool, ks, red):
+    q, k, _ = make_qkv(B, H, S, 128, dt, kind, 17)
+    want = O.pool_scores(O.window_scores(q, k, w, red), pool, ks)
+    got = P.ops.score_window(q.to(DEV), k.to(DEV), w, pool, ks, red).cpu()
+    frac, mx = score_diff(got, want)
+    _report(f"window_scores/{dt}/{kind}/S{S}w{w}{pool}{red}", dict(mismatch_frac=frac, max_ulp=mx))
+    assert mx <= 1 and frac <= SCORE_MISMATCH_FRAC, (frac, mx)
+
+
+@pytest.mark.parametrize("mode", ["div", "rcp"])
+def test_window_scores_scale_modes_and_gqa(P, mode):
+    B, Hkv, g, S, w = 1, 2, 4, 2048, 8
+    q, k, _ = make_qkv(B, Hkv * g, S, 128, "bf16", "gauss", 18)
+    k = k[:, ::g].contiguous()                                               # un-expanded K
+    kx = k[:, :, None].expand(B, Hkv, g, S, 128).reshape(B, Hkv * g, S, 128)
+    want = O.pool_scores(O.window_scores(q, kx, w, "sum", mode), "maxpool", 7)
+    got = P.ops.score_window(q.to(DEV), k.to(DEV), w, "maxpool", 7, "sum", mode, kv_group=g).cpu()
+    got_x = P.ops.score_window(q.to(DEV), kx.to(DEV), w, "maxpool", 7, "sum", mode).cpu()
+    assert torch.equal(got, got_x)                                           # dedup == expanded, bit for bit
+    frac, mx = score_diff(got, want)
+    assert mx <= 1 and frac <= SCORE_MISMATCH_FRAC, (frac, mx)
+
+
+def test_window_scores_32k(P):
+    q, k, _ = make_qkv(1, 4, 32768, 128, "bf16", "gauss", 1234)
+    want = O.pool_scores(O.window_scores(q, k, 8), "maxpool", 7)
+    got = P.ops.score_window(q.to(DEV), k.to(DEV), 8, "maxpool", 7).cpu()
+    frac, mx = score_diff(got, want)
+    _report("window_scores/bf16/gauss/S32768", dict(mismatch_frac=frac, max_ulp=mx))
+    assert mx <= 1 and frac <= SCORE_MISMATCH_FRAC, (frac, mx)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_h2o_scores(P, dt):
+    for S, w in ((256, 8), (1000, 16), (2048, 8)):
+        q, k, _ = make_qkv(1, 2, S, 128, dt, "gauss", 41)
+        want = O.h2o_scores(q, k, w)
+        got = P.ops.score_h2o(q.to(DEV), k.to(DEV), w).cpu()
+        frac, mx = score_diff(got, want)
+        _report(f"h2o_scores/{dt}/S{S}", dict(mismatch_frac=frac, max_ulp=mx))
+        # column sums over S rows in fp32: summation order differs, allow a larger (still 1-ulp) fraction
+        assert mx <= 1 and frac <= 0.05, (frac, mx)
+
+
+# ----------------------------------------------------------------------------------------- end to end
+def _self_consistent(P, cl_out, q, k, v, w, kk, scores_gpu):
+    """indices == canonical top-k of the kernel's own scores; K/V == exact gather of them."""
+    kc, vc, idx = cl_out
+    want_idx = O.topk_canonical(scores_gpu.cpu(), kk)
+    assert torch.equal(idx.cpu().long(), want_idx)
+    kr, vr = O.gather_compact(k, v, want_idx, w)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("S,cap", [(4096, 128), (32768, 128), (8192, 2048)])
+def test_compress_self_consistent_and_match_rate(P, dt, S, cap):
+    w, H = 8, 8
+    q, k, v = make_qkv(1, H, S, 128, dt, "gauss", 1234)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    out = P.ops.compress(qd, kd, vd, w, cap - w, "maxpool", 7, return_indices=True)
+    sg = P.ops.score_window(qd, kd, w, "maxpool", 7)
+    _self_consistent(P, out, q, k, v, w, cap - w, sg)
+    _, _, ridx = O.snapkv_update_kv(k, q, v, w, cap, 7, "maxpool", return_indices=True)
+    same_seq = (out[2].cpu().long() == ridx).all(-1).float().mean().item()
+    same_set = float(np.mean([set(out[2][0, h].tolist()) == set(ridx[0, h].tolist()) for h in range(H)]))
+    _report(f"e2e_gauss/{dt}/S{S}cap{cap}", dict(heads_identical_sequence=same_seq, heads_identical_set=same_set))
+    assert same_set >= 0.5
+
+
+def _margin_ok(s: torch.Tensor, idx: torch.Tensor, ulps=3) -> bool:
+    """True if every pair of distinct selected score values, and the k-th vs the best rejected one,
+    are more than `ulps` apart: then 1-ulp score noise cannot change the selection."""
+    o = ord16(s)
+    for b in range(s.shape[0]):
+        for h in range(s.shape[1]):
+            sel = np.unique(o[b, h][idx[b, h].numpy()])
+            if sel.size > 1 and np.diff(sel).min() <= ulps:
+                return False
+            mask = np.ones(o.shape[-1], bool)
+            mask[idx[b, h].numpy()] = False
+            rest = o[b, h][mask]
+            rest = rest[rest != sel.min()]        # a max-pool plateau cut by the k-th boundary is fine:
+            if rest.size and sel.min() - rest.max() <= ulps:   # the tie rule (lowest index) decides it
+                return False
+    return True
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("S,cap,w", [(4096, 64, 8), (8192, 128, 8), (32768, 128, 8)])
+def test_compress_bit_identical_on_margin_checked_inputs(P, dt, S, cap, w):
+    q, k, v = make_qkv(1, 4, S, 128, dt, "planted", 77)
+    kr, vr, ridx = O.snapkv_update_kv(k, q, v, w, cap, 7, "maxpool", return_indices=True)
+    s = O.pool_scores(O.window_scores(q, k, w), "maxpool", 7)
+    if not _margin_ok(s, ridx):
+        pytest.skip("fixture has no selection margin")
+    cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+    kc, vc = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV), None, 1)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+
+
+def test_pyramid_layers_and_branches(P):
+    S, w, cap = 8192, 8, 128
+    q, k, v = make_qkv(1, 4, S, 128, "bf16", "gauss", 99)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    sg = P.ops.score_window(qd, kd, w, "maxpool", 7).cpu()
+    for layer in (0, 1, 15, 31):
+        cl = P.PyramidKVCluster(num_hidden_layers=32, layer_idx=layer, window_size=w, max_capacity_prompt=cap,
+                                kernel_size=7, pooling="maxpool")
+        branch, kk = O.pyramid_budget(cap, w, 32, layer, S)
+        assert cl.layer_budget(S) == (branch, kk)
+        kc, vc = cl.update_kv(kd, qd, vd, None, 4)
+        assert kc.shape == (1, 4, kk + w, 128)
+        idx = O.topk_canonical(sg, kk)
+        kr, vr = O.gather_compact(k, v, idx, w)
+        assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+    # snap branch and passthrough (returns the input objects themselves, :219)
+    q2, k2, v2 = (t[:, :, :200].contiguous() for t in (qd, kd, vd))
+    cl = P.PyramidKVCluster(num_hidden_layers=32, layer_idx=3, window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+    kc, vc = cl.update_kv(k2, q2, v2, None, 4)
+    assert kc.shape[2] == cap
+    q3, k3, v3 = (t[:, :, :100].contiguous() for t in (qd, kd, vd))
+    kc, vc = cl.update_kv(k3, q3, v3, None, 4)
+    assert kc is k3 and vc is v3
+
+
+def test_h2o_cluster(P):
+    S, w, cap = 1024, 8, 64
+    q, k, v = make_qkv(1, 4, S, 128, "bf16", "gauss", 55)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    out = P.ops.compress(qd, kd, vd, w, cap - w, None, 1, h2o=True, return_indices=True)
+    sg = P.ops.score_h2o(qd, kd, w)
+    _self_consistent(P, out, q, k, v, w, cap - w, sg)
+    cl = P.H2OKVCluster(window_size=w, max_capacity_prompt=cap)
+    kc, vc = cl.update_kv(kd, qd, vd, None, 1)
+    assert torch.equal(kc, out[0]) and torch.equal(vc, out[1])
+
+
+# ----------------------------------------------------------------------------------------- AdaKV / HeadKV
+def test_sort_rows_exact(P):
+    g = torch.Generator().manual_seed(2)
+    for L in (1, 100, 4088, 32760):
+        s = (torch.rand(3, L, generator=g) * (torch.rand(3, L, generator=g) > 0.3)).to(torch.bfloat16)
+        si, sv = P.ops.sort_rows(s.to(DEV))
+        want = torch.sort(s, dim=-1, descending=True, stable=True)
+        assert torch.equal(si.cpu().long(), want.indices) and torch.equal(sv.cpu(), want.values)
+
+
+@pytest.mark.parametrize("dt,pool,ks,floor,norm", [("bf16", "maxpool", 7, 0.2, True), ("fp16", "avgpool", 5, 0.5, False),
+                                                    ("bf16", "maxpool", 7, 0.0, True)])
+def test_ada_budget_and_flat_gather_exact_given_scores(P, dt, pool, ks, floor, norm):
+    """Budget arithmetic + flat gather are integer/byte work: exact vs the oracle when both start from
+    the same scores (the oracle's)."""
+    H, S, w, cap = 8, 4096, 8, 128
+    q, k, v = make_qkv(1, H, S, 128, dt, "gauss", 61)
+    s = O.pool_scores(O.window_scores(q, k, w, "mean"), pool, ks)
+    sidx_ref, cap_ref = O.adakv_head_capacity(s, cap - w, floor, norm, "canonical")
+    si, sv = P.ops.sort_rows(s[0].to(DEV))
+    assert torch.equal(si.cpu().long(), sidx_ref[0])
+    capd = P.ops.ada_budget(sv, cap - w, floor, norm)
+    assert capd.cpu().tolist() == cap_ref[0].tolist()
+    hl, cu = P.ops.ada_metadata(capd, w)
+    caps = capd.cpu().tolist()
+    kf, vf = P.ops.gather_flat(k.to(DEV), v.to(DEV), si, capd, cu, w, sum(caps) + H * w, max(caps))
+    per_head = [sidx_ref[0, h, :caps[h]] for h in range(H)]
+    kr, vr, lens = O._flat_gather(k, v, per_head, w)
+    assert hl.cpu().tolist() == lens
+    assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr)
+
+
+def test_adakv_cluster_metadata_and_consistency(P):
+    H, S, w, cap = 8, 2048, 8, 64
+    q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 62)
+    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2,
+                        normalize=True, layer_idx=0, num_hidden_layers=32)
+    kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
+    kr, vr, meta = O.adakv_update_kv(k, q, v, w, cap, 7, "maxpool", 0.2, True)
+    assert int(cl.head_lens.sum()) == cl.klen_sum == kf.shape[0]
+    assert cl.cu_klen.cpu().tolist() == [0] + np.cumsum(cl.head_lens.cpu().numpy()).tolist()
+    assert cl.cu_qlen.cpu().tolist() == list(range(H + 1)) and cl.cu_offset.cpu().tolist() == list(range(H + 1))
+    assert cl.max_seqlen_k == int(cl.head_lens.max())
+    same = cl.head_lens.cpu().tolist() == meta.head_lens.tolist()
+    _report("adakv/head_lens_identical_to_oracle", same)
+    if same:
+        _report("adakv/kv_identical_to_oracle", bool(torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr)))
+    # not-compressed branch (:700-703)
+    q2, k2, v2 = make_qkv(1, 2, 40, 128, "bf16", "gauss", 53)
+    cl2 = P.AdaKVCluster(window_size=8, kernel_size=7, pooling="maxpool", max_capacity_prompt=64, floor=0.2, normalize=True)
+    kf2, vf2 = cl2.update_kv(k2.to(DEV), q2.to(DEV), v2.to(DEV))
+    assert torch.equal(kf2.cpu(), k2.reshape(-1, 128)) and cl2.head_lens.cpu().tolist() == [40, 40]
+
+
+def test_headkv_cluster(P):
+    H, S, w, cap = 4, 512, 8, 64
+    q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 61)
+    hc = [[10, 70, 56, 33]]
+    cl = P.HeadKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, layer_idx=0,
+                         num_hidden_layers=32, head_capacity=hc)
+    kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
+    assert cl.head_lens.cpu().tolist() == [c + w for c in hc[0]]
+    sg = P.ops.score_window(q.to(DEV), k.to(DEV), w, "maxpool", 7, "mean").cpu()
+    order = torch.sort(sg, dim=-1, descending=True, stable=True).indices
+    per_head = [order[0, h, :hc[0][h]] for h in range(H)]
+    kr, vr, _ = O._flat_gather(k, v, per_head, w)
+    assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr)
+
+
+def test_update_flatten_view(P):
+    H, D = 8, 128
+    g = torch.Generator().manual_seed(4)
+    lens = torch.randint(1, 300, (H,), generator=g, dtype=torch.int32)
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(lens, 0, dtype=torch.int32)])
+    cache = torch.randn(int(cu[-1]), D, generator=g).to(torch.float16)
+    state = torch.randn(H, D, generator=g).to(torch.float16)
+    want = O.update_flatten_view(cache, state, lens, cu)
+    got = P.ops.update_flatten_view(cache.to(DEV), state.to(DEV), lens.to(DEV), cu.to(DEV))
+    assert torch.equal(got.cpu(), want)
+
+
+# ----------------------------------------------------------------------------------------- golden fixtures
+def test_golden_fixtures_through_hip_path(P):
+    """Reference outputs (tests/golden, produced by the real reference on CPU) vs the HIP path.
+    Hard assertions: shapes, metadata arithmetic, and that the selected rows carry the same score-value
+    sequence as the reference's whenever the two score tensors agree on the selected entries."""
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    index = json.load(open(os.path.join(gold, "index.json")))["cases"]
+    stats = {}
+    for c in index:
+        if c["dtype"] == "fp32":
+            continue
+        z = np.load(os.path.join(gold, c["name"] + ".npz"))
+        q, k, v = make_qkv(c["B"], c["H"], c["S"], 128, c["dtype"], c["kind"], c["seed"])
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        pol, w, cap = c["policy"], c["w"], c["cap"]
+        if pol == "snapkv":
+            cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
+            out = cl.update_kv(kd, qd, vd, None, 1)
+        elif pol == "pyramidkv":
+            cl = P.PyramidKVCluster(num_hidden_layers=c["layers"], layer_idx=c["layer"], window_size=w,
+                                    max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
+            out = cl.update_kv(kd, qd, vd, None, 1)
+        elif pol == "h2o":
+            out = P.H2OKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
+        elif pol == "streamingllm":
+            out = P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
+        elif pol == "adakv":
+            cl = P.AdaKVCluster(window_size=w, kernel_size=c["ks"], pooling=c["pool"], max_capacity_prompt=cap,
+                                floor=c["floor"], normalize=c["normalize"], layer_idx=0, num_hidden_layers=32)
+            out = cl.update_kv(kd, qd, vd)
+        else:
+            cl = P.HeadKVCluster(window_size=w, kernel_size=c["ks"], pooling=c["pool"], max_capacity_prompt=cap,
+                                 layer_idx=c["layer"], num_hidden_layers=32, head_capacity=c["head_capacity"])
+            out = cl.update_kv(kd, qd, vd)
+        kc, vc = out
+        if bool(z["passthrough"]):
+            assert kc is kd and vc is vd
+            continue
+        assert tuple(kc.shape) == z["kc"].shape, c["name"]
+        exact = bool(np.array_equal(bits(kc), z["kc"]) and np.array_equal(bits(vc), z["vc"]))
+        # rows may legitimately be permuted inside equal-score groups: compare as multisets of rows
+        same_rows = exact
+        if not exact and kc.dim() == 4:
+            a = np.sort(bits(kc).reshape(kc.shape[0], kc.shape[1], kc.shape[2], -1).view(np.dtype((np.void, 256))), axis=2)
+            b = np.sort(z["kc"].reshape(a.shape[0], a.shape[1], a.shape[2], -1).view(np.dtype((np.void, 256))), axis=2)
+            same_rows = bool(np.array_equal(a, b))
+        stats[c["name"]] = dict(bit_identical=exact, same_row_set=same_rows)
+        if pol in ("adakv", "headkv"):
+            for name in ("cu_qlen", "cu_offset", "cu_head_offset"):
+                assert np.array_equal(getattr(cl, name).cpu().numpy(), z[name]), name
+        if pol == "streamingllm":
+            assert exact
+    _report("golden_through_hip", stats)
+    rate = np.mean([s["same_row_set"] for s in stats.values()])
+    assert rate >= 0.8, stats
