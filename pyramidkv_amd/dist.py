@@ -31,9 +31,9 @@ def allgather_indices(idx_local: torch.Tensor, group: Optional[dist.ProcessGroup
     if world == 1:
         return idx_local
     B, Hl, k = idx_local.shape
-    out = torch.empty(world, B, Hl, k, dtype=idx_local.dtype, device=idx_local.device)
+    out = torch.empty(world * B, Hl, k, dtype=idx_local.dtype, device=idx_local.device)   # rank-major concat
     dist.all_gather_into_tensor(out, idx_local.contiguous(), group=group)
-    return out.permute(1, 0, 2, 3).reshape(B, world * Hl, k)
+    return out.view(world, B, Hl, k).permute(1, 0, 2, 3).reshape(B, world * Hl, k)
 
 
 class HeadShardedCluster:
