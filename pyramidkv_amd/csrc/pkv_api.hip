@@ -52,14 +52,14 @@ struct ProfScope {
 };
 
 // ---- validation ------------------------------------------------------------------------------
-int check_desc(const pkv_desc* d, bool need_topk) {
+int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true) {
   if (!d) return PKV_ERR_NULL;
   if (d->dtype != PKV_BF16 && d->dtype != PKV_F16) return PKV_ERR_DTYPE;
   if (d->D != 128) return PKV_ERR_SHAPE;
   if (d->B < 1 || d->H < 1 || d->S < 2) return PKV_ERR_SHAPE;
   if (d->kv_group < 1 || d->H % d->kv_group) return PKV_ERR_SHAPE;
   if (d->window < 1 || d->window >= d->S) return PKV_ERR_SHAPE;
-  if (d->window > 64 || d->kv_group * d->window > 256) return PKV_ERR_UNSUPPORTED;
+  if (scoring && (d->window > 64 || d->kv_group * d->window > 256)) return PKV_ERR_UNSUPPORTED;
   if (need_topk && (d->topk < 1 || d->topk > d->S - d->window)) return PKV_ERR_SHAPE;
   if (d->pool_kind < 0 || d->pool_kind > 2) return PKV_ERR_SHAPE;
   if (d->pool_kind != PKV_POOL_NONE) {
@@ -263,7 +263,7 @@ int pkv_topk(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scor
 
 int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx,
                        int64_t idx_stride, void* k_out, void* v_out, pkv_stream_t stream) {
-  int rc = check_desc(d, true);
+  int rc = check_desc(d, true, false);
   if (rc) return rc;
   if (!k || !v || !idx || !k_out || !v_out) return PKV_ERR_NULL;
   if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out)) return PKV_ERR_ALIGN;
@@ -275,7 +275,7 @@ int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const in
 
 int pkv_gather_streaming(const pkv_desc* d, const void* k, const void* v, void* k_out, void* v_out,
                          pkv_stream_t stream) {
-  int rc = check_desc(d, true);
+  int rc = check_desc(d, true, false);
   if (rc) return rc;
   if (!k || !v || !k_out || !v_out) return PKV_ERR_NULL;
   if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out)) return PKV_ERR_ALIGN;
@@ -338,7 +338,7 @@ int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, in
 int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32_t* sorted_idx,
                     int64_t idx_stride, const int32_t* head_capacity, const int32_t* cu_klen,
                     void* k_out, void* v_out, pkv_stream_t stream) {
-  int rc = check_desc(d, false);
+  int rc = check_desc(d, false, false);
   if (rc) return rc;
   if (d->B != 1) return PKV_ERR_SHAPE;   // reference asserts bsz == 1 (:724)
   if (!k || !v || !sorted_idx || !head_capacity || !cu_klen || !k_out || !v_out) return PKV_ERR_NULL;

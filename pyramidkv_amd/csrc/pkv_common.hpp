@@ -79,6 +79,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
   return v;
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: usable with nontemporal builtins
+
 union U4 {
   uint4 v;
   uint16_t h[8];

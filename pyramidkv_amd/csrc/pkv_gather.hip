@@ -34,31 +34,44 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
   const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.vptr) + (int64_t)b * p.vs_b + (int64_t)hk * p.vs_h + chunk * 8;
   const int32_t* ib = p.idx ? p.idx + (int64_t)bh * p.idx_stride : nullptr;
 
+  // All loads are unconditional (invalid slots read row 0 and are simply not stored) so that the four
+  // index loads and then the eight 16-B row loads are issued back to back: two dependent memory round
+  // trips per workgroup instead of one per row.
   int src[4];
+  bool ok[4];
+  int gi[4];
+  if (ib) {                                     // uniform branch; the four loads inside are unconditional
+    const int last = nsel > 0 ? nsel - 1 : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r_blk + j * 16 + slot;
+      gi[j] = __builtin_nontemporal_load(ib + (r < last ? r : last));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gi[j] = r_blk + j * 16 + slot;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = r_blk + j * 16 + slot;
-    int s = -1;
-    if (r < nsel) s = ib ? ib[r] : r;
-    else if (r < nrows) s = L + (r - nsel);
-    src[j] = s;
+    ok[j] = r < nrows;
+    const int s = (r < nsel) ? gi[j] : L + (r - nsel);
+    src[j] = ok[j] ? s : 0;
   }
-  uint4 kd[4], vd[4];
+  u32x4 kd[4], vd[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (src[j] >= 0) {
-      kd[j] = *reinterpret_cast<const uint4*>(kb + (int64_t)src[j] * p.ks_s);
-      vd[j] = *reinterpret_cast<const uint4*>(vb + (int64_t)src[j] * p.vs_s);
-    }
+    kd[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (int64_t)src[j] * p.ks_s));
+    vd[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (int64_t)src[j] * p.vs_s));
   }
   uint16_t* ko = reinterpret_cast<uint16_t*>(p.k_out) + chunk * 8;
   uint16_t* vo = reinterpret_cast<uint16_t*>(p.v_out) + chunk * 8;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (src[j] >= 0) {
+    if (ok[j]) {
       const int64_t orow = out_row0 + r_blk + j * 16 + slot;
-      *reinterpret_cast<uint4*>(ko + orow * 128) = kd[j];
-      *reinterpret_cast<uint4*>(vo + orow * 128) = vd[j];
+      __builtin_nontemporal_store(kd[j], reinterpret_cast<u32x4*>(ko + orow * 128));
+      __builtin_nontemporal_store(vd[j], reinterpret_cast<u32x4*>(vo + orow * 128));
     }
   }
 }

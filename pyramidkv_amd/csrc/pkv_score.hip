@@ -154,9 +154,10 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// finalize_kernel: one workgroup = 2032 output positions (+8 halo each side) of one (b,h).
+// finalize_kernel: one workgroup = 1008 output positions (+8 halo each side) of one (b,h);
+// 256 threads x 4 consecutive keys.  Row loads are issued 8 rows at a time (one round trip per 8 rows).
 // ------------------------------------------------------------------------------------------------
-constexpr int FN_SPAN = 2048;              // positions computed per workgroup (256 threads x 8)
+constexpr int FN_SPAN = 1024;              // positions computed per workgroup (256 threads x 4)
 constexpr int FN_OUT = FN_SPAN - 16;       // positions written per workgroup
 
 template <typename T>
@@ -166,85 +167,107 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   __shared__ float rowS[64];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
   const int bh = blockIdx.y;
   const int w = p.w;
   const int L = p.S - w;
   const int64_t rowbase = (int64_t)bh * w;
 
-  // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M)
-  for (int r = wave; r < w; r += 4) {
-    const float2* pr = p.partial + (rowbase + r) * p.nT;
-    float m = -INFINITY;
-    for (int t = lane; t < p.nT; t += 64) m = fmaxf(m, pr[t].x);
-    m = wave_max(m);
-    float z = 0.f;
-    for (int t = lane; t < p.nT; t += 64) {
-      const float2 v = pr[t];
-      if (v.x != -INFINITY) z += v.y * expf(v.x - m);
+  // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M).
+  // 32 lanes per row, 8 rows per pass; partial loads of a pass are independent.
+  {
+    const int sub = tid & 31;
+    for (int r0 = 0; r0 < w; r0 += 8) {
+      const int r = r0 + (tid >> 5);
+      const bool live = r < w;
+      const float2* pr = p.partial + (rowbase + (live ? r : 0)) * p.nT;
+      float m = -INFINITY;
+      for (int t = sub; t < p.nT; t += 32) m = fmaxf(m, pr[t].x);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float z = 0.f;
+      for (int t = sub; t < p.nT; t += 32) {
+        const float2 v = pr[t];
+        if (v.x != -INFINITY) z += v.y * expf(v.x - m);
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+      if (live && sub == 0) { rowM[r] = m; rowS[r] = z; }
     }
-    z = wave_sum(z);
-    if (lane == 0) { rowM[r] = m; rowS[r] = z; }
   }
   __syncthreads();
 
   const int r0 = blockIdx.x * FN_OUT - 8;
-  const int s0 = r0 + tid * 8;
+  const int s0 = r0 + tid * 4;
   const uint16_t pad = (p.pool_kind == 2) ? Elem<T>::neg_inf() : (uint16_t)0;
-  U4 outv;
+  uint16_t ov[4];
   if (s0 >= 0 && s0 < L) {
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const uint16_t* lgp = reinterpret_cast<const uint16_t*>(p.logits) + rowbase * (int64_t)p.Sp + s0;
-    for (int r = 0; r < w; ++r) {
-      U4 u;
-      u.v = *reinterpret_cast<const uint4*>(lgp + (int64_t)r * p.Sp);
-      const float M = rowM[r], Z = rowS[r];
+    for (int rb = 0; rb < w; rb += 8) {
+      uint2 u[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float pr = expf(Elem<T>::to_f32(u.h[e]) - M) / Z;                 // fp32 softmax (:326)
-        acc[e] += Elem<T>::to_f32(Elem<T>::from_f32(pr));                       // .to(dtype), fp32 row accumulate (:327)
+      for (int j = 0; j < 8; ++j) {
+        const int r = rb + j < w ? rb + j : w - 1;
+        u[j] = *reinterpret_cast<const uint2*>(lgp + (int64_t)r * p.Sp);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (rb + j < w) {
+          const float M = rowM[rb + j], Z = rowS[rb + j];
+          const uint16_t h4[4] = {(uint16_t)(u[j].x & 0xffffu), (uint16_t)(u[j].x >> 16),
+                                  (uint16_t)(u[j].y & 0xffffu), (uint16_t)(u[j].y >> 16)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pr = expf(Elem<T>::to_f32(h4[e]) - M) / Z;               // fp32 softmax (:326)
+            acc[e] += Elem<T>::to_f32(Elem<T>::from_f32(pr));                     // .to(dtype); fp32 row accumulate (:327)
+          }
+        }
       }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v = (p.reduce == 1) ? (acc[e] / (float)w) : acc[e];           // mean (:661) or sum (:327)
-      outv.h[e] = (s0 + e < L) ? Elem<T>::from_f32(v) : pad;
+    for (int e = 0; e < 4; ++e) {
+      const float v = (p.reduce == 1) ? (acc[e] / (float)w) : acc[e];             // mean (:661) or sum (:327)
+      ov[e] = (s0 + e < L) ? Elem<T>::from_f32(v) : pad;
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) outv.h[e] = pad;
+    for (int e = 0; e < 4; ++e) ov[e] = pad;
   }
-  *reinterpret_cast<uint4*>(sc + tid * 8) = outv.v;
+  uint2 pk;
+  pk.x = (uint32_t)ov[0] | ((uint32_t)ov[1] << 16);
+  pk.y = (uint32_t)ov[2] | ((uint32_t)ov[3] << 16);
+  *reinterpret_cast<uint2*>(sc + tid * 4) = pk;
   __syncthreads();
 
-  if (tid == 0 || tid == 255 || s0 >= L) return;   // halo threads / nothing to write
-  U4 res;
+  if (tid < 2 || tid >= 254 || s0 >= L) return;   // halo threads / nothing to write
+  uint16_t res[4];
   const int half = p.pool_kernel >> 1;
   if (p.pool_kind == 0) {
-    res = outv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) res[e] = ov[e];
   } else if (p.pool_kind == 2) {                                                 // max_pool1d, -inf padding (:331)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = tid * 8 + e;
+    for (int e = 0; e < 4; ++e) {
+      const int c = tid * 4 + e;
       float m = -INFINITY;
       for (int j = -half; j <= half; ++j) m = fmaxf(m, Elem<T>::to_f32(sc[c + j]));
-      res.h[e] = Elem<T>::from_f32(m);
+      res[e] = Elem<T>::from_f32(m);
     }
   } else {                                                                       // avg_pool1d, zero padding, / kernel (:329)
     const float ks = (float)p.pool_kernel;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = tid * 8 + e;
+    for (int e = 0; e < 4; ++e) {
+      const int c = tid * 4 + e;
       float sum = 0.f;
       for (int j = -half; j <= half; ++j) sum += Elem<T>::to_f32(sc[c + j]);
-      res.h[e] = Elem<T>::from_f32(sum / ks);
+      res[e] = Elem<T>::from_f32(sum / ks);
     }
   }
+  uint2 ro;
+  ro.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+  ro.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
   uint16_t* out = reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride + s0;
-  *reinterpret_cast<uint4*>(out) = res.v;   // stride % 8 == 0 and stride >= roundup(L,8): in bounds
+  *reinterpret_cast<uint2*>(out) = ro;      // stride % 8 == 0, s0 % 4 == 0, stride >= roundup(L,8): aligned, in bounds
 }
 
 template __global__ void logits_kernel<BF16>(LogitsParams);

@@ -48,12 +48,25 @@ __device__ __forceinline__ void reduce_counters(const uint32_t* X, uint32_t* his
   if (part == 0) hist[bin] = s;
 }
 
-// bin b with  above(b) < need <= above(b) + hist[b]  where above(b) = sum_{b'>b} hist[b']
+// bin b with  above(b) < need <= above(b) + hist[b]  where above(b) = sum_{b'>b} hist[b'].
+// One wavefront: lane l owns bins 4l..4l+3; suffix sums across lanes by shuffles.
 __device__ __forceinline__ void find_bin(const uint32_t* hist, uint32_t need, int* out_bin, int* out_above, int tid) {
-  if (tid < 256) {
-    uint32_t above = 0;
-    for (int b2 = tid + 1; b2 < 256; ++b2) above += hist[b2];
-    if (above < need && need <= above + hist[tid]) { *out_bin = tid; *out_above = (int)above; }
+  if (tid < 64) {
+    const uint4 h = reinterpret_cast<const uint4*>(hist)[tid];
+    const uint32_t own = h.x + h.y + h.z + h.w;
+    uint32_t incl = own;                       // inclusive suffix sum over lanes >= tid
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_down(incl, o, 64);
+      if (tid + o < 64) incl += t;
+    }
+    uint32_t above = incl - own;               // bins of higher lanes
+    const uint32_t hv[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+      if (above < need && need <= above + hv[i]) { *out_bin = tid * 4 + i; *out_above = (int)above; }
+      above += hv[i];
+    }
   }
 }
 
@@ -88,25 +101,35 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X[i] = 0;
   __syncthreads();
 
-  // ---- pass A: HBM/L2 -> ordered keys in LDS, histogram of the high byte ----
-  for (int j = 0; j < niter; ++j) {
-    const int base = wave * Lw + j * 512 + lane * 8;
-    U4 u;
-    if (vec_ok && base + 8 <= L) {
-      u.v = *reinterpret_cast<const uint4*>(src + base);
-    } else {
+  // ---- pass A: HBM/L2 -> ordered keys in LDS, histogram of the high byte.  All (<= 8) 16-B loads of
+  //      a lane are issued before the first one is consumed: one memory round trip per workgroup. ----
+  U4 raw[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) u.h[e] = (base + e < L) ? src[base + e] : (uint16_t)0;
-    }
-    U4 ko;
+  for (int j = 0; j < 8; ++j) {
+    if (j < niter) {
+      const int base = wave * Lw + j * 512 + lane * 8;
+      if (vec_ok && base + 8 <= L) {
+        raw[j].v = *reinterpret_cast<const uint4*>(src + base);
+      } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool valid = base + e < L;
-      const uint32_t key = valid ? order_key<T>(u.h[e]) : 0u;
-      ko.h[e] = (uint16_t)key;
-      if (valid) atomicAdd(&X[(key >> 8) * 32 + cslot], inc);
+        for (int e = 0; e < 8; ++e) raw[j].h[e] = (base + e < L) ? src[base + e] : (uint16_t)0;
+      }
     }
-    *reinterpret_cast<uint4*>(keys + base) = ko.v;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < niter) {
+      const int base = wave * Lw + j * 512 + lane * 8;
+      U4 ko;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool valid = base + e < L;
+        const uint32_t key = valid ? order_key<T>(raw[j].h[e]) : 0u;
+        ko.h[e] = (uint16_t)key;
+        if (valid) atomicAdd(&X[(key >> 8) * 32 + cslot], inc);
+      }
+      *reinterpret_cast<uint4*>(keys + base) = ko.v;
+    }
   }
   __syncthreads();
   reduce_counters(X, hist, tid);

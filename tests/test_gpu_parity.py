@@ -389,9 +389,11 @@ def test_update_flatten_view(P):
 
 # ----------------------------------------------------------------------------------------- golden fixtures
 def test_golden_fixtures_through_hip_path(P):
-    """Reference outputs (tests/golden, produced by the real reference on CPU) vs the HIP path.
-    Hard assertions: shapes, metadata arithmetic, and that the selected rows carry the same score-value
-    sequence as the reference's whenever the two score tensors agree on the selected entries."""
+    """Outputs of the REAL reference (tests/golden, produced on CPU) vs the HIP path on the same inputs.
+    The reference's CPU ``topk`` breaks ties arbitrarily, so the statement that can hold bit-for-bit is:
+    the HIP path selects, position by position, rows carrying the SAME SCORE VALUE as the reference's
+    (identical index wherever the value is unique), and its K/V rows are exact copies of the rows it
+    selected.  Var-len metadata (tie-independent) must be identical."""
     gold = os.path.join(os.path.dirname(__file__), "golden")
     index = json.load(open(os.path.join(gold, "index.json")))["cases"]
     stats = {}
@@ -402,43 +404,67 @@ def test_golden_fixtures_through_hip_path(P):
         q, k, v = make_qkv(c["B"], c["H"], c["S"], 128, c["dtype"], c["kind"], c["seed"])
         qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
         pol, w, cap = c["policy"], c["w"], c["cap"]
-        if pol == "snapkv":
-            cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
-            out = cl.update_kv(kd, qd, vd, None, 1)
-        elif pol == "pyramidkv":
-            cl = P.PyramidKVCluster(num_hidden_layers=c["layers"], layer_idx=c["layer"], window_size=w,
-                                    max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
-            out = cl.update_kv(kd, qd, vd, None, 1)
-        elif pol == "h2o":
-            out = P.H2OKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
+        pool = None if c["pool"] == "none" else c["pool"]
+        if pol in ("snapkv", "pyramidkv", "h2o"):
+            if pol == "snapkv":
+                cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
+                kk = cap - w
+            elif pol == "pyramidkv":
+                cl = P.PyramidKVCluster(num_hidden_layers=c["layers"], layer_idx=c["layer"], window_size=w,
+                                        max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
+                kk = cl.layer_budget(c["S"])[1]
+            else:
+                cl = P.H2OKVCluster(window_size=w, max_capacity_prompt=cap)
+                kk = cap - w
+            kc, vc = cl.update_kv(kd, qd, vd, None, 1)
+            if bool(z["passthrough"]):
+                assert kc is kd and vc is vd
+                continue
+            assert tuple(kc.shape) == z["kc"].shape, c["name"]
+            _, _, idx = P.ops.compress(qd, kd, vd, w, kk, pool, c["ks"], h2o=(pol == "h2o"), return_indices=True)
+            idx = idx.cpu().long()
+            kr, vr = O.gather_compact(k, v, idx, w)
+            assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), c["name"]       # exact copies of the selected rows
+            s = O.h2o_scores(q, k, w) if pol == "h2o" else O.pool_scores(O.window_scores(q, k, w), pool, c["ks"])
+            ref_idx = torch.from_numpy(z["idx"].astype(np.int64))
+            equiv = O.equivalent_selection(idx, ref_idx, s)
+            exact = bool(np.array_equal(bits(kc), z["kc"]))
+            stats[c["name"]] = dict(same_score_sequence_as_reference=equiv, bit_identical_to_reference=exact)
         elif pol == "streamingllm":
-            out = P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
-        elif pol == "adakv":
-            cl = P.AdaKVCluster(window_size=w, kernel_size=c["ks"], pooling=c["pool"], max_capacity_prompt=cap,
-                                floor=c["floor"], normalize=c["normalize"], layer_idx=0, num_hidden_layers=32)
-            out = cl.update_kv(kd, qd, vd)
+            kc, vc = P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
+            assert np.array_equal(bits(kc), z["kc"]) and np.array_equal(bits(vc), z["vc"])
+            stats[c["name"]] = dict(same_score_sequence_as_reference=True, bit_identical_to_reference=True)
         else:
-            cl = P.HeadKVCluster(window_size=w, kernel_size=c["ks"], pooling=c["pool"], max_capacity_prompt=cap,
-                                 layer_idx=c["layer"], num_hidden_layers=32, head_capacity=c["head_capacity"])
-            out = cl.update_kv(kd, qd, vd)
-        kc, vc = out
-        if bool(z["passthrough"]):
-            assert kc is kd and vc is vd
-            continue
-        assert tuple(kc.shape) == z["kc"].shape, c["name"]
-        exact = bool(np.array_equal(bits(kc), z["kc"]) and np.array_equal(bits(vc), z["vc"]))
-        # rows may legitimately be permuted inside equal-score groups: compare as multisets of rows
-        same_rows = exact
-        if not exact and kc.dim() == 4:
-            a = np.sort(bits(kc).reshape(kc.shape[0], kc.shape[1], kc.shape[2], -1).view(np.dtype((np.void, 256))), axis=2)
-            b = np.sort(z["kc"].reshape(a.shape[0], a.shape[1], a.shape[2], -1).view(np.dtype((np.void, 256))), axis=2)
-            same_rows = bool(np.array_equal(a, b))
-        stats[c["name"]] = dict(bit_identical=exact, same_row_set=same_rows)
-        if pol in ("adakv", "headkv"):
-            for name in ("cu_qlen", "cu_offset", "cu_head_offset"):
-                assert np.array_equal(getattr(cl, name).cpu().numpy(), z[name]), name
-        if pol == "streamingllm":
-            assert exact
+            if pol == "adakv":
+                cl = P.AdaKVCluster(window_size=w, kernel_size=c["ks"], pooling=c["pool"], max_capacity_prompt=cap,
+                                    floor=c["floor"], normalize=c["normalize"], layer_idx=0, num_hidden_layers=32)
+            else:
+                cl = P.HeadKVCluster(window_size=w, kernel_size=c["ks"], pooling=c["pool"], max_capacity_prompt=cap,
+                                     layer_idx=c["layer"], num_hidden_layers=32, head_capacity=c["head_capacity"])
+            kf, vf = cl.update_kv(kd, qd, vd)
+            for name in ("head_lens", "cu_klen", "cu_qlen", "cu_offset", "cu_head_offset"):
+                assert np.array_equal(getattr(cl, name).cpu().numpy(), z[name]), (c["name"], name)
+            assert cl.klen_sum == int(z["klen_sum"]) and cl.max_seqlen_k == int(z["max_seqlen_k"])
+            assert tuple(kf.shape) == z["kc"].shape
+            exact = bool(np.array_equal(bits(kf), z["kc"]) and np.array_equal(bits(vf), z["vc"]))
+            equiv = exact
+            if "idx_flat" in z.files and not exact:
+                # window tails must be exact; selected rows must carry the reference's score values
+                s = O.pool_scores(O.window_scores(q, k, w, "mean"), pool, c["ks"])
+                hl = z["head_lens"]
+                off, roff, equiv = 0, 0, True
+                kfc = kf.cpu()
+                for h in range(c["H"]):
+                    n = int(hl[h]) - w
+                    rows = bits(kfc[off:off + n])
+                    table = {bits(k[0, h, j]).tobytes(): j for j in range(c["S"] - w - 1, -1, -1)}
+                    mine = torch.tensor([table[r.tobytes()] for r in rows], dtype=torch.int64)
+                    ref = torch.from_numpy(z["idx_flat"][roff:roff + n].astype(np.int64))
+                    equiv &= O.equivalent_selection(mine[None], ref[None], s[0, h][None])
+                    assert torch.equal(kfc[off + n:off + n + w], k[0, h, -w:])
+                    off += int(hl[h])
+                    roff += n
+            stats[c["name"]] = dict(same_score_sequence_as_reference=bool(equiv), bit_identical_to_reference=exact)
     _report("golden_through_hip", stats)
-    rate = np.mean([s["same_row_set"] for s in stats.values()])
-    assert rate >= 0.8, stats
+    rate = np.mean([s["same_score_sequence_as_reference"] for s in stats.values()])
+    assert rate >= 0.9, stats
