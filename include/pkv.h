@@ -153,6 +153,10 @@ enum pkv_kernel_id {
 int pkv_prof_enable(int on);                                   /* returns previous state */
 int pkv_prof_read(double* ms_sum, int64_t* launches, int reset); /* arrays of PKV_K_COUNT; syncs events */
 
+/* ---- debug / test hooks (not part of the drop-in surface) ---- */
+int pkv_debug_topk_trace(void* device_u64x8); /* NULL disables; row 0 of every later top-k launch stamps 7 phase clocks */
+int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream); /* the kernels' exp(), for accuracy tests */
+
 #ifdef __cplusplus
 }
 #endif

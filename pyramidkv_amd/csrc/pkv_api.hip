@@ -5,6 +5,7 @@
 #include "pkv_kernels.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 
@@ -13,6 +14,16 @@ using namespace pkv;
 namespace {
 
 thread_local int g_last_hip = 0;
+unsigned long long* g_topk_trace = nullptr;   // debug hook, see pkv_debug_topk_trace
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+// logits kernel shape: keys per workgroup (128 = 32 keys/wave, ~7 workgroups per CU; 256 = 64 keys/wave)
+// and nontemporal K loads.  Defaults are the measured best (profiles/); env vars exist for A/B runs.
+int logits_tile() { static int t = env_int("PKV_LOGITS_TILE", 128) == 256 ? 256 : 128; return t; }
+int logits_nt() { static int t = env_int("PKV_LOGITS_NT", 1); return t; }
 
 inline int hip_fail(hipError_t e) { g_last_hip = (int)e; return PKV_ERR_HIP; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -79,8 +90,8 @@ struct WsLayout {
 
 WsLayout ws_layout(const pkv_desc* d) {
   WsLayout w;
-  w.nT = (d->S + 255) / 256;
-  w.Sp = w.nT * 256;
+  w.nT = (d->S + logits_tile() - 1) / logits_tile();
+  w.Sp = (d->S + 255) / 256 * 256;
   w.Lp = (int)align_up((size_t)(d->S - d->window), 8);
   const size_t rows = (size_t)d->B * d->H * d->window;
   size_t o = 0;
@@ -100,7 +111,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   lp.logits = ws + L.off_logits;
   lp.partial = reinterpret_cast<float2*>(ws + L.off_partial);
   lp.B = d->B; lp.H = d->H; lp.S = d->S; lp.w = d->window; lp.G = d->kv_group;
-  lp.Sp = L.Sp; lp.nT = L.nT;
+  lp.Sp = L.Sp; lp.nT = L.nT; lp.tile = logits_tile(); lp.nt = logits_nt();
   lp.qs_b = d->q_stride[0]; lp.qs_h = d->q_stride[1]; lp.qs_s = d->q_stride[2];
   lp.ks_b = d->k_stride[0]; lp.ks_h = d->k_stride[1]; lp.ks_s = d->k_stride[2];
   lp.scale_mode = d->scale_mode;
@@ -156,7 +167,7 @@ int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t strid
   if (L < 1 || k < 1 || k > L || rows < 1) return PKV_ERR_SHAPE;
   TopkParams tp;
   tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
-  tp.idx_out = idx; tp.idx_stride = idx_stride;
+  tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace;
   const size_t lds = topk_lds_bytes(L, k, &tp.Lw, &tp.kpad);
   if (lds > 160 * 1024 || 16 * (size_t)tp.Lw > 65536) return PKV_ERR_UNSUPPORTED;
   ProfScope ps(PKV_K_TOPK, st);
@@ -360,6 +371,14 @@ int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const vo
   fp.cache = cache; fp.state = state; fp.head_lens = head_lens; fp.cu_klen = cu_klen; fp.out = out;
   fp.H = H; fp.row_bytes = head_dim * 2;
   hipError_t e = launch_flatten(fp, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+/* ---- debug / test hooks (not part of the drop-in surface) ---- */
+int pkv_debug_topk_trace(void* device_u64x8) { g_topk_trace = static_cast<unsigned long long*>(device_u64x8); return PKV_OK; }
+
+int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream) {
+  hipError_t e = launch_debug_exp(in, out, n, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }
 

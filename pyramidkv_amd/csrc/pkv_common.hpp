@@ -51,6 +51,26 @@ template <typename T> __device__ __forceinline__ uint32_t order_key(uint16_t h) 
   return (h & 0x8000u) ? (uint32_t)(uint16_t)(~h) : (uint32_t)(h | 0x8000u);
 }
 
+// exp(x) for x <= ~0 (softmax arguments): Cody-Waite reduction + v_exp_f32 on |t| <= 0.5, ~1.5 ulp.
+// The model-dtype rounding that follows every use absorbs it exactly as it absorbs ATen's own
+// vectorised exp (tests bound the disagreement with the CPU oracle).  -inf and x < -104 give +0.
+__device__ __forceinline__ float pkv_exp(float x) {
+  if (!(x > -104.0f)) return (x != x) ? x : 0.0f;
+  const float L2E = 1.44269504088896340736f;
+  const float n = rintf(x * L2E);
+  float r = fmaf(n, -0.693145751953125f, x);             // ln2_hi: 12 trailing zero bits, n*ln2_hi exact
+  r = fmaf(n, -1.42860682030941723212e-6f, r);           // ln2_lo
+  const float p = __builtin_amdgcn_exp2f(r * L2E);       // v_exp_f32, argument in [-0.5, 0.5]
+  return ldexpf(p, (int)n);
+}
+
+// correctly rounded x / c for a loop-invariant c (rc = RN(1/c)): one Newton-Markstein correction step.
+__device__ __forceinline__ float div_const(float x, float c, float rc) {
+  const float q = x * rc;
+  const float r = fmaf(-q, c, x);
+  return fmaf(r, rc, q);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ float wave_max(float v) {

@@ -110,4 +110,13 @@ hipError_t launch_flatten(const FlattenParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+__global__ void debug_exp_kernel(const float* in, float* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = pkv_exp(in[i]);
+}
+hipError_t launch_debug_exp(const float* in, float* out, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(debug_exp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
+
 }  // namespace pkv

@@ -35,7 +35,7 @@ template <> struct Mfma2<F16> {
 template <typename T>
 __device__ __forceinline__ float logit_chain(float acc, const H2OParams& p) {
   float x = Elem<T>::to_f32(Elem<T>::from_f32(acc));                       // matmul output dtype (:544)
-  x = (p.scale_mode == 0) ? (x / p.sqrt_d) : (x * p.rcp_sqrt_d);           // / math.sqrt(head_dim)
+  x = (p.scale_mode == 0) ? div_const(x, p.sqrt_d, p.rcp_sqrt_d) : (x * p.rcp_sqrt_d);   // / math.sqrt(head_dim), exact
   return Elem<T>::to_f32(Elem<T>::from_f32(x));
 }
 
@@ -89,9 +89,9 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
       }
       const float mn = fmaxf(m[n], mx);
       if (mn != -INFINITY) {
-        float z = Z[n] * expf(m[n] - mn);
+        float z = Z[n] * pkv_exp(m[n] - mn);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z += expf(x[r] - mn);
+        for (int r = 0; r < 4; ++r) z += pkv_exp(x[r] - mn);
         Z[n] = z;
         m[n] = mn;
       }
@@ -105,11 +105,11 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
     for (int o = 16; o <= 32; o <<= 1) {
       const float mo = __shfl_xor(mm, o, 64), zo = __shfl_xor(zz, o, 64);
       const float mn = fmaxf(mm, mo);
-      const float za = (mm == -INFINITY) ? 0.f : zz * expf(mm - mn);
-      const float zb = (mo == -INFINITY) ? 0.f : zo * expf(mo - mn);
+      const float za = (mm == -INFINITY) ? 0.f : zz * pkv_exp(mm - mn);
+      const float zb = (mo == -INFINITY) ? 0.f : zo * pkv_exp(mo - mn);
       mm = mn; zz = za + zb;
     }
-    if (lg == 0 && qi[n] < S) rs[qi[n]] = make_float2(mm, zz);
+    if (lg == 0 && qi[n] < S) rs[qi[n]] = make_float2(mm, 1.0f / zz);   // (row max, 1 / row sum): ATen CPU softmax multiplies
   }
 }
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + lg * 4 + r;
         const float x = logit_chain<T>(acc[r], p);       // keys < L never touch the masked corner
-        const float pr = expf(x - st[r].x) / st[r].y;    // fp32 softmax (:553)
+        const float pr = pkv_exp(x - st[r].x) * st[r].y;    // fp32 softmax (:553)
         const float pq = Elem<T>::to_f32(Elem<T>::from_f32(pr));
         if (i < S) col[n] += pq;                         // sum over all rows, fp32 (:554)
       }

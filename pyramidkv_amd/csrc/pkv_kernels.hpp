@@ -12,6 +12,8 @@ struct LogitsParams {
   float2* partial;   // [B*H*w][nT] (tile row max, tile sum exp)
   int B, H, S, w, G; // G = kv_group
   int Sp, nT;
+  int tile;          // keys per workgroup: 128 or 256 (nT = ceil(S / tile))
+  int nt;            // nontemporal K loads
   int64_t qs_b, qs_h, qs_s;
   int64_t ks_b, ks_h, ks_s;
   int scale_mode;
@@ -34,6 +36,7 @@ struct TopkParams {
   const int32_t* k_per_row;
   int32_t* idx_out;      // [rows][idx_stride]
   int64_t idx_stride;
+  unsigned long long* trace;   // debug: phase timestamps of row 0 (may be null)
   int Lw;                // keys per wave (multiple of 512)
   int kpad;              // power of two >= k (bitonic path) or k (rank path)
 };
@@ -101,6 +104,7 @@ hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
 hipError_t launch_ada_metadata(int H, int w, const int32_t* cap, int32_t* head_lens, int32_t* cu_klen, hipStream_t st);
 hipError_t launch_flatten(const FlattenParams& p, hipStream_t st);
+hipError_t launch_debug_exp(const float* in, float* out, int64_t n, hipStream_t st);
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st);
 hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st);
 

@@ -19,29 +19,33 @@ typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8_t;
 
 template <typename T> struct Mfma;
 template <> struct Mfma<BF16> {
-  static __device__ __forceinline__ f32x4 run(uint4 a, uint4 b, f32x4 c) {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
 };
 template <> struct Mfma<F16> {
-  static __device__ __forceinline__ f32x4 run(uint4 a, uint4 b, f32x4 c) {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
 
 // ------------------------------------------------------------------------------------------------
-// logits_kernel: one workgroup = 256 keys of one (batch, kv-head group); 4 waves x 64 keys.
+// logits_kernel: one workgroup = 4*KPW keys of one (batch, kv-head group); 4 waves x KPW keys.
 // MFMA 16x16x32: A = 16 keys x 32 d (K tile, rows), B = 32 d x 16 columns (window queries).
 // A column c of the group is (head h0 + c / w, window row c % w); C = kv_group * w columns.
 // D element [key i][col j] sits in lane (j + 16*(i/4)), register i%4.
+// KPW = 32 keeps the K fragments at 32 VGPRs so ~7 workgroups stay resident per CU: the HBM queue
+// never drains while other workgroups are in their MFMA / LDS / store phases.  K is streamed once
+// and never re-read: nontemporal loads (NT) keep it out of the way of the logits in L2.
 // ------------------------------------------------------------------------------------------------
-constexpr int LG_TILE = 256;              // keys per workgroup
-constexpr int LG_LROW = LG_TILE + 8;      // LDS row stride in elements (528 B: 16-B aligned, <=2-way write conflicts)
-
-template <typename T>
+template <typename T, int KPW, bool NT>
 __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
+  constexpr int TILE = 4 * KPW;            // keys per workgroup
+  constexpr int LROW = TILE + 8;           // LDS row stride in elements (16-B aligned rows, <=2-way write conflicts)
+  constexpr int NSUB = KPW / 16;           // 16-key MFMA subtiles per wave
+  constexpr int CH = TILE / 8;             // 16-B chunks (lanes) per logits row of the tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint16_t* tile = reinterpret_cast<uint16_t*>(smem_raw);  // [C][LG_LROW]
+  uint16_t* tile = reinterpret_cast<uint16_t*>(smem_raw);  // [C][LROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -60,17 +64,20 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   const int li = lane & 15;   // key within 16-subtile (A rows) / column within 16-tile (B cols)
   const int lg = lane >> 4;   // 8-element d-chunk within a 32-wide k-step
 
-  // ---- issue all K loads of this wave: 4 subtiles x 4 k-steps x 16 B per lane ----
+  // ---- issue all K loads of this wave: NSUB subtiles x 4 k-steps x 16 B per lane ----
   const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
-  const int s_wave = t_idx * LG_TILE + wave * 64;
-  uint4 kf[4][4];
+  const int s_wave = t_idx * TILE + wave * KPW;
+  u32x4 kf[NSUB][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < NSUB; ++t) {
     int s = s_wave + t * 16 + li;
     s = s < S ? s : S - 1;  // clamp: stay in bounds; out-of-range keys are masked out of the stats below
     const uint16_t* row = kbase + (int64_t)s * p.ks_s + lg * 8;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) kf[t][kk] = *reinterpret_cast<const uint4*>(row + kk * 32);
+    for (int kk = 0; kk < 4; ++kk) {
+      const u32x4* ptr = reinterpret_cast<const u32x4*>(row + kk * 32);
+      kf[t][kk] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
+    }
   }
 
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b;
@@ -80,31 +87,32 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   for (int n = 0; n < ntile_c; ++n) {
     // B fragments: column c = n*16 + li -> Q[b, h0 + c/w, S - w + c%w, kk*32 + lg*8 ..]
     const int c = n * 16 + li;
-    uint4 qf[4];
+    u32x4 qf[4];
     if (c < C) {
       const int hh = h0 + c / w;
       const int rr = c - (c / w) * w;
       const uint16_t* qrow = qb + (int64_t)hh * p.qs_h + (int64_t)(L + rr) * p.qs_s + lg * 8;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const uint4*>(qrow + kk * 32);
+      for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const u32x4*>(qrow + kk * 32);
     } else {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) qf[kk] = make_uint4(0, 0, 0, 0);
+      for (int kk = 0; kk < 4; ++kk) qf[kk] = u32x4{0, 0, 0, 0};
     }
     const int rr_c = c % w;  // window row of this lane's column
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NSUB; ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(kf[t][kk], qf[kk], acc);
       // epilogue: three roundings to the model dtype, as the reference materialises them
-      const int key0 = wave * 64 + t * 16 + lg * 4;        // key within the tile of acc[0]
-      const int sg0 = t_idx * LG_TILE + key0;              // global key index
+      const int key0 = wave * KPW + t * 16 + lg * 4;       // key within the tile of acc[0]
+      const int sg0 = t_idx * TILE + key0;                 // global key index
       uint16_t o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = Elem<T>::to_f32(Elem<T>::from_f32(acc[r]));                     // matmul output dtype (:317)
-        x = (p.scale_mode == 0) ? (x / p.sqrt_d) : (x * p.rcp_sqrt_d);            // "/ math.sqrt(head_dim)" (:317)
+        x = (p.scale_mode == 0) ? div_const(x, p.sqrt_d, p.rcp_sqrt_d)            // "/ math.sqrt(head_dim)" (:317), exact
+                                : (x * p.rcp_sqrt_d);
         uint16_t y = Elem<T>::from_f32(x);
         const int s = sg0 + r;
         if (s >= L && (s - L) > rr_c)                                              // strict upper corner (:318-324)
@@ -115,22 +123,22 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
         uint2 pk;
         pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
         pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-        *reinterpret_cast<uint2*>(tile + c * LG_LROW + key0) = pk;
+        *reinterpret_cast<uint2*>(tile + c * LROW + key0) = pk;
       }
     }
   }
   __syncthreads();
 
-  // ---- per-row tile statistics + coalesced 16-B store of the logits tile ----
+  // ---- per-row tile statistics + coalesced 16-B store of the logits tile (CH lanes per row) ----
   const int64_t rowbase = ((int64_t)b * p.H + h0) * w;
   uint16_t* lg_out = reinterpret_cast<uint16_t*>(p.logits);
-  const int items = C * 32;  // 32 chunks of 8 keys per row
+  const int items = C * CH;
   for (int it = tid; it < items; it += 256) {
-    const int row = it >> 5;
-    const int chunk = it & 31;
+    const int row = it / CH;
+    const int chunk = it % CH;
     U4 u;
-    u.v = *reinterpret_cast<const uint4*>(tile + row * LG_LROW + chunk * 8);
-    const int s0 = t_idx * LG_TILE + chunk * 8;
+    u.v = *reinterpret_cast<const uint4*>(tile + row * LROW + chunk * 8);
+    const int s0 = t_idx * TILE + chunk * 8;
     float xv[8];
     float m = -INFINITY;
 #pragma unroll
@@ -139,15 +147,15 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
       if (s0 + e < S) m = fmaxf(m, xv[e]);
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));   // 32-lane half = one row
+    for (int o = CH / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));   // CH-lane group = one row
     float l = 0.f;
     if (m != -INFINITY) {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        if (s0 + e < S) l += expf(xv[e] - m);
+        if (s0 + e < S) l += pkv_exp(xv[e] - m);
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    for (int o = CH / 2; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
     if (chunk == 0) p.partial[(rowbase + row) * p.nT + t_idx] = make_float2(m, l);
     *reinterpret_cast<uint4*>(lg_out + (rowbase + row) * (int64_t)p.Sp + s0) = u.v;
   }
@@ -187,11 +195,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
       float z = 0.f;
       for (int t = sub; t < p.nT; t += 32) {
         const float2 v = pr[t];
-        if (v.x != -INFINITY) z += v.y * expf(v.x - m);
+        if (v.x != -INFINITY) z += v.y * pkv_exp(v.x - m);
       }
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
-      if (live && sub == 0) { rowM[r] = m; rowS[r] = z; }
+      if (live && sub == 0) { rowM[r] = m; rowS[r] = 1.0f / z; }   // ATen CPU softmax: x * (1 / sum)
     }
   }
   __syncthreads();
@@ -213,12 +221,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (rb + j < w) {
-          const float M = rowM[rb + j], Z = rowS[rb + j];
+          const float M = rowM[rb + j], RZ = rowS[rb + j];
           const uint16_t h4[4] = {(uint16_t)(u[j].x & 0xffffu), (uint16_t)(u[j].x >> 16),
                                   (uint16_t)(u[j].y & 0xffffu), (uint16_t)(u[j].y >> 16)};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float pr = expf(Elem<T>::to_f32(h4[e]) - M) / Z;               // fp32 softmax (:326)
+            const float pr = pkv_exp(Elem<T>::to_f32(h4[e]) - M) * RZ;            // fp32 softmax (:326)
             acc[e] += Elem<T>::to_f32(Elem<T>::from_f32(pr));                     // .to(dtype); fp32 row accumulate (:327)
           }
         }
@@ -270,17 +278,20 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   *reinterpret_cast<uint2*>(out) = ro;      // stride % 8 == 0, s0 % 4 == 0, stride >= roundup(L,8): aligned, in bounds
 }
 
-template __global__ void logits_kernel<BF16>(LogitsParams);
-template __global__ void logits_kernel<F16>(LogitsParams);
-template __global__ void finalize_kernel<BF16>(FinalizeParams);
-template __global__ void finalize_kernel<F16>(FinalizeParams);
-
 hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
   const int C = p.G * p.w;
   dim3 grid(p.nT, p.B * (p.H / p.G));
-  size_t lds = (size_t)C * LG_LROW * sizeof(uint16_t);
-  if (dtype == 0) hipLaunchKernelGGL(logits_kernel<BF16>, grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(logits_kernel<F16>, grid, dim3(256), lds, st, p);
+  const int tile = p.tile;
+  const size_t lds = (size_t)C * (tile + 8) * sizeof(uint16_t);
+#define PKV_LAUNCH(TT, KPW, NT) hipLaunchKernelGGL((logits_kernel<TT, KPW, NT>), grid, dim3(256), lds, st, p)
+  if (dtype == 0) {
+    if (tile == 128) { if (p.nt) PKV_LAUNCH(BF16, 32, true); else PKV_LAUNCH(BF16, 32, false); }
+    else             { if (p.nt) PKV_LAUNCH(BF16, 64, true); else PKV_LAUNCH(BF16, 64, false); }
+  } else {
+    if (tile == 128) { if (p.nt) PKV_LAUNCH(F16, 32, true); else PKV_LAUNCH(F16, 32, false); }
+    else             { if (p.nt) PKV_LAUNCH(F16, 64, true); else PKV_LAUNCH(F16, 64, false); }
+  }
+#undef PKV_LAUNCH
   return hipGetLastError();
 }
 

@@ -98,6 +98,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   const int cslot = lane & 31;
   const int niter = Lw / 512;
 
+#define PKV_STAMP(i) do { if (p.trace && tid == 0 && row == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
+  PKV_STAMP(0);
   for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X[i] = 0;
   __syncthreads();
 
@@ -132,10 +134,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     }
   }
   __syncthreads();
+  PKV_STAMP(1);
   reduce_counters(X, hist, tid);
   __syncthreads();
   find_bin(hist, (uint32_t)k, &misc[0], &misc[1], tid);
   __syncthreads();
+  PKV_STAMP(2);
   const uint32_t b1 = (uint32_t)misc[0];
   const int n_above1 = misc[1];
 
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   __syncthreads();
   find_bin(hist, (uint32_t)(k - n_above1), &misc[2], &misc[3], tid);
   __syncthreads();
+  PKV_STAMP(3);
   const uint32_t Tkey = (b1 << 8) | (uint32_t)misc[2];
   const int n_gt = n_above1 + misc[3];          // keys strictly above the threshold
   const int n_eq_take = k - n_gt;               // lowest-index keys equal to the threshold
@@ -180,6 +185,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     if (lane == 0) { wcnt[wave] = cg; wcnt[16 + wave] = ce; }
   }
   __syncthreads();   // also: every read of the counters in X is done; X becomes `sel`
+  PKV_STAMP(4);
   uint32_t run_g = 0, run_e = 0;
   for (int w2 = 0; w2 < wave; ++w2) { run_g += wcnt[w2]; run_e += wcnt[16 + w2]; }
   uint32_t* sel = X;
@@ -223,6 +229,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   else { kpad = 1; while (kpad < k) kpad <<= 1; }
   for (int i = k + tid; i < kpad; i += TK_THREADS) sel[i] = 0;
   __syncthreads();
+  PKV_STAMP(5);
 
   int32_t* out = p.idx_out + (int64_t)row * p.idx_stride;
   if (k <= TK_RANK_MAX) {
@@ -253,6 +260,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     }
     for (int i = tid; i < k; i += TK_THREADS) out[i] = (int32_t)(0xffffu - (sel[i] & 0xffffu));
   }
+  PKV_STAMP(6);
+#undef PKV_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------

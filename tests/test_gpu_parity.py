@@ -50,6 +50,30 @@ def score_diff(a: torch.Tensor, b: torch.Tensor):
     return float((da > 0).mean()), int(da.max())
 
 
+# ----------------------------------------------------------------------------------------- numerics helpers
+def test_kernel_exp_accuracy(P):
+    """The kernels' exp() (Cody-Waite + v_exp_f32) vs float64: <= 2 ulp over the softmax argument range,
+    exact zeros below the fp32 underflow threshold, exp(0) == 1."""
+    N = P._native
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([-torch.rand(200000, generator=g) * 104, -torch.rand(50000, generator=g) * 2,
+                   torch.tensor([0.0, -0.0, -1e-30, -87.3, -88.0, -103.9, -104.0, -110.0, -1e30, -float("inf")])]).float()
+    xd = x.to(DEV)
+    out = torch.empty_like(xd)
+    N.check(N.lib.pkv_debug_exp(xd.data_ptr(), out.data_ptr(), xd.numel(), N.stream_ptr()), "debug_exp")
+    got = out.cpu().double()
+    want = torch.exp(x.double())
+    w32 = want.float()
+    assert got[x == 0].eq(1.0).all() and got[x <= -104.0].eq(0.0).all()
+    norm = want > 1.2e-38                                     # normal range: ulp-relative error
+    rel = ((got - want).abs() / want)[norm]
+    ulp = (rel / 2 ** -24).max().item()
+    sub = ~norm & (x > -104.0)
+    abs_sub = (got - want).abs()[sub].max().item() if sub.any() else 0.0
+    _report("pkv_exp_max_ulp_error", dict(normal_range_ulp=ulp, subnormal_abs=abs_sub))
+    assert ulp <= 2.0 and abs_sub <= 3e-45
+
+
 # ----------------------------------------------------------------------------------------- gather
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,H,S,w,k", [(1, 4, 512, 8, 56), (2, 3, 4096, 32, 2016), (1, 32, 32768, 8, 120),
