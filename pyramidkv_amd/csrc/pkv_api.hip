@@ -22,8 +22,9 @@ int env_int(const char* name, int dflt) {
 }
 // logits kernel shape: keys per workgroup (128 = 32 keys/wave, ~7 workgroups per CU; 256 = 64 keys/wave)
 // and nontemporal K loads.  Defaults are the measured best (profiles/); env vars exist for A/B runs.
-int logits_tile() { static int t = env_int("PKV_LOGITS_TILE", 128) == 256 ? 256 : 128; return t; }
-int logits_nt() { static int t = env_int("PKV_LOGITS_NT", 1); return t; }
+int logits_tile() { static int t = env_int("PKV_LOGITS_TILE", 256) == 128 ? 128 : 256; return t; }
+int logits_nt() { static int t = env_int("PKV_LOGITS_NT", 0); return t; }
+int logits_ablate() { static int t = env_int("PKV_LOGITS_ABLATE", 0); return t; }   // measurement only: wrong results
 
 inline int hip_fail(hipError_t e) { g_last_hip = (int)e; return PKV_ERR_HIP; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -111,7 +112,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   lp.logits = ws + L.off_logits;
   lp.partial = reinterpret_cast<float2*>(ws + L.off_partial);
   lp.B = d->B; lp.H = d->H; lp.S = d->S; lp.w = d->window; lp.G = d->kv_group;
-  lp.Sp = L.Sp; lp.nT = L.nT; lp.tile = logits_tile(); lp.nt = logits_nt();
+  lp.Sp = L.Sp; lp.nT = L.nT; lp.tile = logits_tile(); lp.nt = logits_nt(); lp.ablate = logits_ablate();
   lp.qs_b = d->q_stride[0]; lp.qs_h = d->q_stride[1]; lp.qs_s = d->q_stride[2];
   lp.ks_b = d->k_stride[0]; lp.ks_h = d->k_stride[1]; lp.ks_s = d->k_stride[2];
   lp.scale_mode = d->scale_mode;
@@ -170,6 +171,10 @@ int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t strid
   tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace;
   const size_t lds = topk_lds_bytes(L, k, &tp.Lw, &tp.kpad);
   if (lds > 160 * 1024 || 16 * (size_t)tp.Lw > 65536) return PKV_ERR_UNSUPPORTED;
+  {
+    const size_t xw = (size_t)(tp.kpad > 8192 ? tp.kpad : 8192);
+    tp.dual = lds >= (size_t)2 * 16 * tp.Lw + 4 * xw + 4 * 256 + 4 * 64 + 4 * 8192 ? 1 : 0;
+  }
   ProfScope ps(PKV_K_TOPK, st);
   hipError_t e = launch_topk(dtype, rows, tp, lds, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);

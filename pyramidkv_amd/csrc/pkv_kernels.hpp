@@ -14,6 +14,7 @@ struct LogitsParams {
   int Sp, nT;
   int tile;          // keys per workgroup: 128 or 256 (nT = ceil(S / tile))
   int nt;            // nontemporal K loads
+  int ablate;        // 0 = full kernel; 1..3 = measurement-only ablations (PKV_LOGITS_ABLATE)
   int64_t qs_b, qs_h, qs_s;
   int64_t ks_b, ks_h, ks_s;
   int scale_mode;
@@ -38,7 +39,8 @@ struct TopkParams {
   int64_t idx_stride;
   unsigned long long* trace;   // debug: phase timestamps of row 0 (may be null)
   int Lw;                // keys per wave (multiple of 512)
-  int kpad;              // power of two >= k (bitonic path) or k (rank path)
+  int kpad;              // words reserved for the selection list (see topk_lds_bytes)
+  int dual;              // second 32 KB counter / radix scratch region present in LDS
 };
 
 struct SortParams {

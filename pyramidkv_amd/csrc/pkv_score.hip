@@ -80,6 +80,15 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
     }
   }
 
+  if (p.ablate == 3) {   // measurement aid: K loads only
+    u32x4 a = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NSUB; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) a ^= kf[t][kk];
+    if ((a.x ^ a.y ^ a.z ^ a.w) == 0x12345678u) p.partial[0] = make_float2(0.f, 0.f);
+    return;
+  }
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b;
   const float fmin_v = Elem<T>::finfo_min();
   const int ntile_c = (C + 15) >> 4;
@@ -104,6 +113,10 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(kf[t][kk], qf[kk], acc);
+      if (p.ablate == 2) {   // measurement aid: loads + MFMA only
+        if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e30f) p.partial[0] = make_float2(0.f, 0.f);
+        continue;
+      }
       // epilogue: three roundings to the model dtype, as the reference materialises them
       const int key0 = wave * KPW + t * 16 + lg * 4;       // key within the tile of acc[0]
       const int sg0 = t_idx * TILE + key0;                 // global key index
@@ -127,6 +140,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
       }
     }
   }
+  if (p.ablate >= 1) return;   // measurement aid: no statistics / logits store
   __syncthreads();
 
   // ---- per-row tile statistics + coalesced 16-B store of the logits tile (CH lanes per row) ----
@@ -181,24 +195,38 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   const int64_t rowbase = (int64_t)bh * w;
 
   // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M).
-  // 32 lanes per row, 8 rows per pass; partial loads of a pass are independent.
+  // 32 lanes per row, 8 rows per pass; every lane issues its (<= 8 per chunk) partial loads back to
+  // back (clamped index, masked afterwards) so a pass costs ONE memory round trip, not nT/32.
   {
     const int sub = tid & 31;
     for (int r0 = 0; r0 < w; r0 += 8) {
       const int r = r0 + (tid >> 5);
       const bool live = r < w;
       const float2* pr = p.partial + (rowbase + (live ? r : 0)) * p.nT;
-      float m = -INFINITY;
-      for (int t = sub; t < p.nT; t += 32) m = fmaxf(m, pr[t].x);
+      float m = -INFINITY, z = 0.f;
+      for (int c0 = 0; c0 < p.nT; c0 += 256) {          // 256 partials per chunk (S <= 32k at tile 128: one chunk)
+        float2 pv[8];
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      float z = 0.f;
-      for (int t = sub; t < p.nT; t += 32) {
-        const float2 v = pr[t];
-        if (v.x != -INFINITY) z += v.y * pkv_exp(v.x - m);
+        for (int i = 0; i < 8; ++i) {
+          const int t = c0 + sub + 32 * i;
+          pv[i] = pr[t < p.nT ? t : p.nT - 1];
+          if (t >= p.nT) pv[i] = make_float2(-INFINITY, 0.f);
+        }
+        float mc = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mc = fmaxf(mc, pv[i].x);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+        const float mn = fmaxf(m, mc);
+        float zc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (pv[i].x != -INFINITY) zc += pv[i].y * pkv_exp(pv[i].x - mn);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) zc += __shfl_xor(zc, o, 64);
+        z = (m == -INFINITY ? 0.f : z * pkv_exp(m - mn)) + zc;
+        m = mn;
       }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
       if (live && sub == 0) { rowM[r] = m; rowS[r] = 1.0f / z; }   // ATen CPU softmax: x * (1 / sum)
     }
   }

@@ -19,19 +19,24 @@ namespace pkv {
 constexpr int TK_THREADS = 1024;
 constexpr int TK_WAVES = 16;
 constexpr int TK_CNT_WORDS = 256 * 32;   // counters[bin][lane&31], lo16 = lanes 0-31, hi16 = lanes 32-63
-constexpr int TK_RANK_MAX = 1024;        // k <= this: rank-by-counting; above: bitonic network
+constexpr int TK_RANK_MAX = 512;         // k <= this: order by rank counting (O(k^2), no barriers)
+constexpr int TK_RADIX_MAX = 4096;       // k <= this (and LDS allows): stable 2-pass LSD radix ordering
+constexpr size_t TK_LDS_LIMIT = 160 * 1024;
 
+// LDS layout: keys u16[16*Lw] | X u32[max(8192,kpad)] | hist u32[256] | misc u32[64] | X2 u32[8192] (if it fits)
 size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out) {
   int per_wave = (L + TK_WAVES - 1) / TK_WAVES;
   int Lw = ((per_wave + 511) / 512) * 512;
   if (Lw < 512) Lw = 512;
   int kpad;
-  if (k <= TK_RANK_MAX) kpad = (k + 3) & ~3;
+  if (k <= TK_RADIX_MAX) kpad = (k + 3) & ~3;
   else { kpad = 1; while (kpad < k) kpad <<= 1; }
   if (Lw_out) *Lw_out = Lw;
   if (kpad_out) *kpad_out = kpad;
   size_t xwords = (size_t)(kpad > TK_CNT_WORDS ? kpad : TK_CNT_WORDS);
-  return (size_t)2 * TK_WAVES * Lw + 4 * xwords + 4 * 256 + 4 * 64;
+  size_t base = (size_t)2 * TK_WAVES * Lw + 4 * xwords + 4 * 256 + 4 * 64;
+  if (base + 4 * TK_CNT_WORDS <= TK_LDS_LIMIT) base += 4 * TK_CNT_WORDS;   // second counter / radix scratch region
+  return base;
 }
 
 // sum the bank-spread counters into hist[256]
@@ -70,6 +75,68 @@ __device__ __forceinline__ void find_bin(const uint32_t* hist, uint32_t need, in
   }
 }
 
+// One stable LSD radix pass over k composites (key<<16 | ~idx) by descending key byte `byte` (0/1).
+// Element i lives in wave i / (ept*64): list order == (wave, e, lane) order, which makes the pass stable.
+// table: u32[16][256] scratch; tot: u32[256] scratch.
+__device__ __forceinline__ void radix_pass(const uint32_t* src, uint32_t* dst, uint32_t* table, uint32_t* tot,
+                                           int k, int ept, int byte, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < TK_WAVES * 256; i += TK_THREADS) table[i] = 0;
+  __syncthreads();
+  uint32_t comp[4], dig[4], lrank[4];
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < ept) {
+      const int i = wave * ept * 64 + e * 64 + lane;
+      const bool valid = i < k;
+      comp[e] = valid ? src[i] : 0u;
+      const uint32_t d = 255u - ((comp[e] >> (16 + 8 * byte)) & 255u);     // ascending in d == descending in key
+      dig[e] = d;
+      uint64_t peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bb = __ballot(valid && bit);
+        peers &= bit ? bb : ~bb;
+      }
+      const uint32_t before = (uint32_t)__popcll(peers & lt);
+      const uint32_t cnt = (uint32_t)__popcll(peers);
+      uint32_t prev = 0;
+      if (valid) prev = table[wave * 256 + d];            // every peer reads the same running count ...
+      lrank[e] = prev + before;
+      if (valid && before == 0) table[wave * 256 + d] = prev + cnt;   // ... then the group leader advances it
+    }
+  }
+  __syncthreads();
+  if (tid < 256) {                                        // per digit: exclusive prefix over the 16 waves
+    uint32_t run = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < TK_WAVES; ++w2) {
+      const uint32_t c = table[w2 * 256 + tid];
+      table[w2 * 256 + tid] = run;
+      run += c;
+    }
+    tot[tid] = run;
+  }
+  __syncthreads();
+  if (tid < 64) {                                         // exclusive prefix over the 256 digit totals
+    const uint4 h = reinterpret_cast<const uint4*>(tot)[tid];
+    const uint32_t own = h.x + h.y + h.z + h.w;
+    const uint32_t excl = wave_incl_scan_u32(own) - own;
+    reinterpret_cast<uint4*>(tot)[tid] = make_uint4(excl, excl + h.x, excl + h.x + h.y, excl + h.x + h.y + h.z);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < ept) {
+      const int i = wave * ept * 64 + e * 64 + lane;
+      if (i < k) dst[tot[dig[e]] + table[wave * 256 + dig[e]] + lrank[e]] = comp[e];
+    }
+  }
+  __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -89,8 +156,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   uint32_t* X = reinterpret_cast<uint32_t*>(smem + (size_t)2 * Lk);        // counters, later `sel`
   const int xwords = p.kpad > TK_CNT_WORDS ? p.kpad : TK_CNT_WORDS;
   uint32_t* hist = X + xwords;
-  int* misc = reinterpret_cast<int*>(hist + 256);
-  uint32_t* wcnt = reinterpret_cast<uint32_t*>(misc + 16);
+  uint32_t* miscu = hist + 256;
+  int* misc = reinterpret_cast<int*>(miscu);
+  uint32_t* wcnt = miscu + 16;
+  uint32_t* X2 = miscu + 64;                                               // only if p.dual
+  const bool dual = p.dual != 0;
 
   const uint16_t* src = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)row * p.scores_stride;
   const bool vec_ok = ((p.scores_stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
@@ -100,11 +170,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
 
 #define PKV_STAMP(i) do { if (p.trace && tid == 0 && row == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
   PKV_STAMP(0);
-  for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X[i] = 0;
-  __syncthreads();
-
-  // ---- pass A: HBM/L2 -> ordered keys in LDS, histogram of the high byte.  All (<= 8) 16-B loads of
-  //      a lane are issued before the first one is consumed: one memory round trip per workgroup. ----
+  // ---- pass A: HBM/L2 -> ordered keys in LDS, histogram of the high byte.  All (<= 8) 16-B loads of a
+  //      lane are issued first; the counter arrays are zeroed while they are in flight. ----
   U4 raw[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -118,6 +185,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       }
     }
   }
+  for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (j < niter) {
@@ -144,8 +213,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   const int n_above1 = misc[1];
 
   // ---- pass B: histogram of the low byte inside bin b1 ----
-  for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X[i] = 0;
-  __syncthreads();
+  uint32_t* XB = dual ? X2 : X;
+  if (!dual) {
+    for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X[i] = 0;
+    __syncthreads();
+  }
   for (int j = 0; j < niter; ++j) {
     const int base = wave * Lw + j * 512 + lane * 8;
     U4 kv;
@@ -153,11 +225,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const uint32_t key = kv.h[e];
-      if (key != 0u && (key >> 8) == b1) atomicAdd(&X[(key & 255u) * 32 + cslot], inc);
+      if (key != 0u && (key >> 8) == b1) atomicAdd(&XB[(key & 255u) * 32 + cslot], inc);
     }
   }
   __syncthreads();
-  reduce_counters(X, hist, tid);
+  reduce_counters(XB, hist, tid);
   __syncthreads();
   find_bin(hist, (uint32_t)(k - n_above1), &misc[2], &misc[3], tid);
   __syncthreads();
@@ -190,8 +262,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   for (int w2 = 0; w2 < wave; ++w2) { run_g += wcnt[w2]; run_e += wcnt[16 + w2]; }
   uint32_t* sel = X;
 
-  // ---- pass D: compaction.  composite = key<<16 | (0xffff - index): descending composite order
-  //      == (value desc, index asc) ----
+  // ---- pass D: compaction in index order.  composite = key<<16 | (0xffff - index): descending
+  //      composite order == (value desc, index asc).  Chunks without any candidate are skipped. ----
   for (int j = 0; j < niter; ++j) {
     const int base = wave * Lw + j * 512 + lane * 8;
     U4 kv;
@@ -203,31 +275,33 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       cg += key > Tkey;
       ce += key == Tkey;
     }
-    const uint32_t packed = (ce << 16) | cg;      // per-iteration totals <= 512 each
+    if (__ballot((cg | ce) != 0) == 0ull) continue;            // wave-uniform
+    const uint32_t packed = (ce << 16) | cg;                   // per-iteration totals <= 512 each
     const uint32_t incl = wave_incl_scan_u32(packed);
     const uint32_t excl = incl - packed;
     uint32_t og = run_g + (excl & 0xffffu);
     uint32_t oe = run_e + (excl >> 16);
+    if (cg | ce) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const uint32_t key = kv.h[e];
-      const uint32_t comp = (key << 16) | (0xffffu - (uint32_t)(base + e));
-      if (key > Tkey) {
-        sel[og++] = comp;
-      } else if (key == Tkey) {
-        if ((int)oe < n_eq_take) sel[n_gt + oe] = comp;
-        ++oe;
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t key = kv.h[e];
+        const uint32_t comp = (key << 16) | (0xffffu - (uint32_t)(base + e));
+        if (key > Tkey) {
+          sel[og++] = comp;
+        } else if (key == Tkey) {
+          if ((int)oe < n_eq_take) sel[n_gt + oe] = comp;
+          ++oe;
+        }
       }
     }
     const uint32_t tot = __shfl(incl, 63, 64);
     run_g += tot & 0xffffu;
     run_e += tot >> 16;
   }
-  // padding of the ordering network / rank loop: composite 0 sorts last and is never emitted
   int kpad;
-  if (k <= TK_RANK_MAX) kpad = (k + 3) & ~3;
+  if (k <= TK_RADIX_MAX) kpad = (k + 3) & ~3;
   else { kpad = 1; while (kpad < k) kpad <<= 1; }
-  for (int i = k + tid; i < kpad; i += TK_THREADS) sel[i] = 0;
+  for (int i = k + tid; i < kpad; i += TK_THREADS) sel[i] = 0;   // padding: composite 0 sorts last, never emitted
   __syncthreads();
   PKV_STAMP(5);
 
@@ -244,11 +318,24 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       }
       out[rank] = (int32_t)(0xffffu - (mine & 0xffffu));
     }
+  } else if (k <= TK_RADIX_MAX && dual) {
+    // the compacted list is index-ordered within equal keys, so a STABLE sort by key alone gives the
+    // canonical order: two LSD radix passes (low byte, high byte), ping-pong sel <-> X2[4096..]
+    uint32_t* table = X2;                 // [16][256]
+    uint32_t* sel2 = X2 + TK_WAVES * 256; // [4096]
+    const int ept = (k + TK_THREADS - 1) / TK_THREADS;
+    radix_pass(sel, sel2, table, hist, k, ept, 0, tid);
+    radix_pass(sel2, sel, table, hist, k, ept, 1, tid);
+    for (int i = tid; i < k; i += TK_THREADS) out[i] = (int32_t)(0xffffu - (sel[i] & 0xffffu));
   } else {
-    // bitonic network, descending
-    for (int size = 2; size <= kpad; size <<= 1) {
+    // bitonic network, descending (kpad is a power of two here)
+    int kp2 = 1;
+    while (kp2 < k) kp2 <<= 1;
+    for (int i = kpad + tid; i < kp2; i += TK_THREADS) sel[i] = 0;
+    __syncthreads();
+    for (int size = 2; size <= kp2; size <<= 1) {
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int t = tid; t < (kpad >> 1); t += TK_THREADS) {
+        for (int t = tid; t < (kp2 >> 1); t += TK_THREADS) {
           const int a = 2 * t - (t & (stride - 1));
           const int b = a + stride;
           const bool desc = (a & size) == 0;
