@@ -130,6 +130,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   fp.pool_kind = d->pool_kind;
   fp.pool_kernel = d->pool_kind == PKV_POOL_NONE ? 1 : d->pool_kernel;
   fp.reduce = d->reduce;
+  fp.trace = g_topk_trace ? g_topk_trace + 8 : nullptr;
   {
     ProfScope ps(PKV_K_FINALIZE, st);
     hipError_t e = launch_finalize(d->dtype, fp, st);
@@ -384,6 +385,12 @@ int pkv_debug_topk_trace(void* device_u64x8) { g_topk_trace = static_cast<unsign
 
 int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream) {
   hipError_t e = launch_debug_exp(in, out, n, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int pkv_debug_round(int32_t dtype, const float* in, void* out, int64_t n, pkv_stream_t stream) {
+  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  hipError_t e = launch_debug_round(dtype, in, static_cast<uint16_t*>(out), n, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }
 

@@ -18,11 +18,9 @@ template <typename T> struct Elem;
 
 template <> struct Elem<BF16> {
   static __device__ __forceinline__ float to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-  static __device__ __forceinline__ uint16_t from_f32(float f) {  // RNE, NaN kept quiet
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+  static __device__ __forceinline__ uint16_t from_f32(float f) {  // v_cvt_pk_bf16_f32: hardware RNE (checked
+    __bf16 b = (__bf16)f;                                         // bit-for-bit against torch in the GPU tests)
+    return __builtin_bit_cast(uint16_t, b);
   }
   static __device__ __forceinline__ float finfo_min() { return __uint_as_float(0xff7f0000u); }  // -3.3895e38
   static __device__ __forceinline__ uint16_t neg_inf() { return 0xff80u; }
@@ -55,13 +53,16 @@ template <typename T> __device__ __forceinline__ uint32_t order_key(uint16_t h) 
 // The model-dtype rounding that follows every use absorbs it exactly as it absorbs ATen's own
 // vectorised exp (tests bound the disagreement with the CPU oracle).  -inf and x < -104 give +0.
 __device__ __forceinline__ float pkv_exp(float x) {
-  if (!(x > -104.0f)) return (x != x) ? x : 0.0f;
+  // branch-free: evaluate on a clamped argument, then select the underflow / NaN results
+  const float xc = fmaxf(x, -104.0f);
   const float L2E = 1.44269504088896340736f;
-  const float n = rintf(x * L2E);
-  float r = fmaf(n, -0.693145751953125f, x);             // ln2_hi: 12 trailing zero bits, n*ln2_hi exact
+  const float n = rintf(xc * L2E);
+  float r = fmaf(n, -0.693145751953125f, xc);            // ln2_hi: 12 trailing zero bits, n*ln2_hi exact
   r = fmaf(n, -1.42860682030941723212e-6f, r);           // ln2_lo
   const float p = __builtin_amdgcn_exp2f(r * L2E);       // v_exp_f32, argument in [-0.5, 0.5]
-  return ldexpf(p, (int)n);
+  const float e = ldexpf(p, (int)n);
+  const float lo = (x != x) ? x : 0.0f;
+  return (x > -104.0f) ? e : lo;
 }
 
 // correctly rounded x / c for a loop-invariant c (rc = RN(1/c)): one Newton-Markstein correction step.
@@ -88,14 +89,14 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// inclusive prefix sum across the 64 lanes of a wave
+// inclusive prefix sum across the 64 lanes of a wave: DPP row shifts + row broadcasts (pure VALU, no LDS)
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-  const int l = lane_id();
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t t = __shfl_up(v, o, 64);
-    if (l >= o) v += t;
-  }
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
   return v;
 }
 

@@ -119,4 +119,14 @@ hipError_t launch_debug_exp(const float* in, float* out, int64_t n, hipStream_t 
   return hipGetLastError();
 }
 
+template <typename T> __global__ void debug_round_kernel(const float* in, uint16_t* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = Elem<T>::from_f32(in[i]);
+}
+hipError_t launch_debug_round(int dtype, const float* in, uint16_t* out, int64_t n, hipStream_t st) {
+  if (dtype == 0) hipLaunchKernelGGL(debug_round_kernel<BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+  else hipLaunchKernelGGL(debug_round_kernel<F16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
+
 }  // namespace pkv

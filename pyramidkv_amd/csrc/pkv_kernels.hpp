@@ -28,6 +28,7 @@ struct FinalizeParams {
   int64_t scores_stride;
   int B, H, S, w, Sp, nT;
   int pool_kind, pool_kernel, reduce;
+  unsigned long long* trace;   // debug: phase timestamps of block (0,0) (may be null)
 };
 
 struct TopkParams {
@@ -107,6 +108,7 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
 hipError_t launch_ada_metadata(int H, int w, const int32_t* cap, int32_t* head_lens, int32_t* cu_klen, hipStream_t st);
 hipError_t launch_flatten(const FlattenParams& p, hipStream_t st);
 hipError_t launch_debug_exp(const float* in, float* out, int64_t n, hipStream_t st);
+hipError_t launch_debug_round(int dtype, const float* in, uint16_t* out, int64_t n, hipStream_t st);
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st);
 hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st);
 

@@ -163,10 +163,10 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 #pragma unroll
     for (int o = CH / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));   // CH-lane group = one row
     float l = 0.f;
-    if (m != -INFINITY) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (s0 + e < S) l += pkv_exp(xv[e] - m);
+    for (int e = 0; e < 8; ++e) {
+      const float t = pkv_exp(xv[e] - m);
+      l += (s0 + e < S && m != -INFINITY) ? t : 0.f;
     }
 #pragma unroll
     for (int o = CH / 2; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
@@ -193,6 +193,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   const int w = p.w;
   const int L = p.S - w;
   const int64_t rowbase = (int64_t)bh * w;
+#define PKV_FSTAMP(i) do { if (p.trace && tid == 0 && blockIdx.x == 1 && bh == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
+  PKV_FSTAMP(0);
 
   // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M).
   // 32 lanes per row, 8 rows per pass; every lane issues its (<= 8 per chunk) partial loads back to
@@ -220,8 +222,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
         const float mn = fmaxf(m, mc);
         float zc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (pv[i].x != -INFINITY) zc += pv[i].y * pkv_exp(pv[i].x - mn);
+        for (int i = 0; i < 8; ++i) {
+          const float t = pv[i].y * pkv_exp(pv[i].x - mn);       // exp(-inf - mn) == 0
+          zc += (pv[i].x != -INFINITY) ? t : 0.f;
+        }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) zc += __shfl_xor(zc, o, 64);
         z = (m == -INFINITY ? 0.f : z * pkv_exp(m - mn)) + zc;
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
     }
   }
   __syncthreads();
+  PKV_FSTAMP(1);
 
   const int r0 = blockIdx.x * FN_OUT - 8;
   const int s0 = r0 + tid * 4;
@@ -272,8 +277,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   uint2 pk;
   pk.x = (uint32_t)ov[0] | ((uint32_t)ov[1] << 16);
   pk.y = (uint32_t)ov[2] | ((uint32_t)ov[3] << 16);
+  PKV_FSTAMP(2);
   *reinterpret_cast<uint2*>(sc + tid * 4) = pk;
   __syncthreads();
+  PKV_FSTAMP(3);
 
   if (tid < 2 || tid >= 254 || s0 >= L) return;   // halo threads / nothing to write
   uint16_t res[4];
@@ -281,22 +288,36 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   if (p.pool_kind == 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) res[e] = ov[e];
-  } else if (p.pool_kind == 2) {                                                 // max_pool1d, -inf padding (:331)
+  } else {
+    // the 20 staged scores around this thread's 4 positions: 5 x 8-byte LDS reads issued together
+    float v[20];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = tid * 4 + e;
-      float m = -INFINITY;
-      for (int j = -half; j <= half; ++j) m = fmaxf(m, Elem<T>::to_f32(sc[c + j]));
-      res[e] = Elem<T>::from_f32(m);
+    for (int i = 0; i < 5; ++i) {
+      const uint2 t = *reinterpret_cast<const uint2*>(sc + tid * 4 - 8 + i * 4);
+      v[i * 4 + 0] = Elem<T>::to_f32((uint16_t)(t.x & 0xffffu));
+      v[i * 4 + 1] = Elem<T>::to_f32((uint16_t)(t.x >> 16));
+      v[i * 4 + 2] = Elem<T>::to_f32((uint16_t)(t.y & 0xffffu));
+      v[i * 4 + 3] = Elem<T>::to_f32((uint16_t)(t.y >> 16));
     }
-  } else {                                                                       // avg_pool1d, zero padding, / kernel (:329)
-    const float ks = (float)p.pool_kernel;
+    if (p.pool_kind == 2) {                                                      // max_pool1d, -inf padding (:331)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = tid * 4 + e;
-      float sum = 0.f;
-      for (int j = -half; j <= half; ++j) sum += Elem<T>::to_f32(sc[c + j]);
-      res[e] = Elem<T>::from_f32(sum / ks);
+      for (int e = 0; e < 4; ++e) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = -8; j <= 8; ++j)
+          if (j >= -half && j <= half) m = fmaxf(m, v[8 + e + j]);
+        res[e] = Elem<T>::from_f32(m);
+      }
+    } else {                                                                     // avg_pool1d, zero padding, / kernel (:329)
+      const float ks = (float)p.pool_kernel;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = -8; j <= 8; ++j)
+          if (j >= -half && j <= half) sum += v[8 + e + j];                      // left-to-right fp32 sum
+        res[e] = Elem<T>::from_f32(sum / ks);
+      }
     }
   }
   uint2 ro;
@@ -304,6 +325,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   ro.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
   uint16_t* out = reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride + s0;
   *reinterpret_cast<uint2*>(out) = ro;      // stride % 8 == 0, s0 % 4 == 0, stride >= roundup(L,8): aligned, in bounds
+  if (p.trace && tid == 2 && blockIdx.x == 1 && bh == 0) p.trace[4] = (unsigned long long)clock64();
+#undef PKV_FSTAMP
 }
 
 hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   }
   for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
   __syncthreads();
+  if (p.trace && tid == 0 && row == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[7] = (unsigned long long)clock64(); }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (j < niter) {
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         const bool valid = base + e < L;
         const uint32_t key = valid ? order_key<T>(raw[j].h[e]) : 0u;
         ko.h[e] = (uint16_t)key;
-        if (valid) atomicAdd(&X[(key >> 8) * 32 + cslot], inc);
+        if (valid) atomicAdd(&X[(key >> 8) * 32 + cslot], inc);   // ~16 cycles per wave-instruction, any lane count
       }
       *reinterpret_cast<uint4*>(keys + base) = ko.v;
     }

@@ -74,6 +74,31 @@ def test_kernel_exp_accuracy(P):
     assert ulp <= 2.0 and abs_sub <= 3e-45
 
 
+@pytest.mark.parametrize("dt,tdt", [(0, torch.bfloat16), (1, torch.float16)])
+def test_kernel_rounding_is_torch_rne(P, dt, tdt):
+    """Every rounding point uses Elem<T>::from_f32 (v_cvt_pk_bf16_f32 / v_cvt_f16_f32): must equal
+    torch's fp32 -> dtype cast bit for bit, ties, subnormals and overflow included."""
+    N = P._native
+    g = torch.Generator().manual_seed(0)
+    mant = torch.randint(0, 1 << 23, (400000,), generator=g, dtype=torch.int32)
+    expo = torch.randint(0, 255, (400000,), generator=g, dtype=torch.int32)
+    sign = torch.randint(0, 2, (400000,), generator=g, dtype=torch.int32)
+    rnd = ((sign << 31) | (expo << 23) | mant).view(torch.float32)
+    # exact ties and near-ties around every 16-bit boundary of a few exponents
+    base = torch.arange(0, 1 << 16, dtype=torch.int32)
+    ties = torch.cat([((e << 23) | ((base & 0x7f) << 16) | off).view(torch.float32)
+                      for e in (1, 100, 127, 142, 143, 254) for off in (0x7fff, 0x8000, 0x8001)])
+    f16_edge = torch.tensor([65504.0, 65519.99, 65520.0, 65536.0, 6.1035e-5, 6.0975e-5, 5.96e-8, 2.98e-8, 2.9802322e-8,
+                             2.99e-8, 8.94e-8, 1e-8, 0.0, -0.0, float("inf"), -float("inf"), 3.3895314e38, 3.4e38])
+    x = torch.cat([rnd, ties, f16_edge, -f16_edge])
+    xd = x.to(DEV)
+    out = torch.empty(x.numel(), dtype=torch.int16, device=DEV)
+    N.check(N.lib.pkv_debug_round(dt, xd.data_ptr(), out.data_ptr(), x.numel(), N.stream_ptr()), "debug_round")
+    got = out.cpu().numpy().view(np.uint16)
+    want = bits(x.to(tdt))
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+
+
 # ----------------------------------------------------------------------------------------- gather
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,H,S,w,k", [(1, 4, 512, 8, 56), (2, 3, 4096, 32, 2016), (1, 32, 32768, 8, 120),

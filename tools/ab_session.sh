@@ -1,5 +1,4 @@
 #!/bin/bash
-# Session 4: parity + top-k trace + logits ablation ladder + bench.
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,8 +8,6 @@ cd $R
 timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.txt 2>&1
 echo "pytest exit $?" >> $O/pytest.txt
 python tools/topk_trace.py > $O/topk_trace.json 2> $O/topk_trace.err
-for ab in 0 1 2 3; do
-  PKV_LOGITS_ABLATE=$ab timeout 600 python tools/sweep.py quick > $O/sweep_ablate${ab}.json 2> $O/sweep_ablate${ab}.err
-done
+timeout 600 python tools/sweep.py quick > $O/sweep_quick.json 2> $O/sweep_quick.err
 timeout 900 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
-tail -4 $O/pytest.txt; cat $O/bench.json
+tail -4 $O/pytest.txt; cat $O/topk_trace.json
