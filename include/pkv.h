@@ -155,6 +155,7 @@ int pkv_prof_read(double* ms_sum, int64_t* launches, int reset); /* arrays of PK
 
 /* ---- debug / test hooks (not part of the drop-in surface) ---- */
 int pkv_debug_topk_trace(void* device_u64x8); /* NULL disables; row 0 of every later top-k launch stamps 7 phase clocks */
+int pkv_debug_wg_trace(void* device_u64);     /* NULL disables; 2*262144 u64: per-workgroup (start,end) wall clock, 100 MHz */
 int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream); /* the kernels' exp(), for accuracy tests */
 int pkv_debug_round(int32_t dtype, const float* in, void* out, int64_t n, pkv_stream_t stream); /* fp32 -> dtype rounding used at every rounding point */
 

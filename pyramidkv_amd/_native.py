@@ -61,6 +61,7 @@ def _load():
         "pkv_gather_flat": (C.c_int, [dp, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
         "pkv_update_flatten_view": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
         "pkv_debug_topk_trace": (C.c_int, [vp]),
+        "pkv_debug_wg_trace": (C.c_int, [vp]),
         "pkv_debug_exp": (C.c_int, [vp, vp, i64, vp]),
         "pkv_debug_round": (C.c_int, [i32, vp, vp, i64, vp]),
         "pkv_prof_enable": (C.c_int, [C.c_int]),

@@ -15,6 +15,7 @@ namespace {
 
 thread_local int g_last_hip = 0;
 unsigned long long* g_topk_trace = nullptr;   // debug hook, see pkv_debug_topk_trace
+unsigned long long* g_wg_trace = nullptr;     // debug hook, see pkv_debug_wg_trace (2*262144 u64)
 
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -86,7 +87,7 @@ int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true) {
 
 struct WsLayout {
   int Sp, nT, Lp;
-  size_t off_logits, off_partial, off_scores, off_idx, off_rowstat, total;
+  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_rowstat, total;
 };
 
 WsLayout ws_layout(const pkv_desc* d) {
@@ -100,19 +101,20 @@ WsLayout ws_layout(const pkv_desc* d) {
   w.off_partial = o; o = align_up(o + rows * w.nT * sizeof(float2), 256);
   w.off_scores = o;  o = align_up(o + (size_t)d->B * d->H * w.Lp * 2, 256);
   w.off_idx = o;     o = align_up(o + (size_t)d->B * d->H * (d->topk > 0 ? d->topk : 1) * 4, 256);
+  w.off_cmax = o;    o = align_up(o + (size_t)d->B * d->H * (w.Lp / 8) * 2, 256);
   w.off_rowstat = o; o = align_up(o + (size_t)d->B * d->H * d->S * sizeof(float2), 256);   // H2O only
   w.total = o;
   return w;
 }
 
 int do_score_window(const pkv_desc* d, const void* q, const void* k, void* scores, int64_t stride,
-                    char* ws, const WsLayout& L, hipStream_t st) {
+                    char* ws, const WsLayout& L, hipStream_t st, bool want_cmax = false) {
   LogitsParams lp;
   lp.q = q; lp.k = k;
   lp.logits = ws + L.off_logits;
   lp.partial = reinterpret_cast<float2*>(ws + L.off_partial);
   lp.B = d->B; lp.H = d->H; lp.S = d->S; lp.w = d->window; lp.G = d->kv_group;
-  lp.Sp = L.Sp; lp.nT = L.nT; lp.tile = logits_tile(); lp.nt = logits_nt(); lp.ablate = logits_ablate();
+  lp.Sp = L.Sp; lp.nT = L.nT; lp.tile = logits_tile(); lp.nt = logits_nt(); lp.ablate = logits_ablate(); lp.wgtrace = g_wg_trace;
   lp.qs_b = d->q_stride[0]; lp.qs_h = d->q_stride[1]; lp.qs_s = d->q_stride[2];
   lp.ks_b = d->k_stride[0]; lp.ks_h = d->k_stride[1]; lp.ks_s = d->k_stride[2];
   lp.scale_mode = d->scale_mode;
@@ -130,7 +132,9 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   fp.pool_kind = d->pool_kind;
   fp.pool_kernel = d->pool_kind == PKV_POOL_NONE ? 1 : d->pool_kernel;
   fp.reduce = d->reduce;
+  fp.cmax = want_cmax ? ws + L.off_cmax : nullptr; fp.cmax_stride = L.Lp / 8;
   fp.trace = g_topk_trace ? g_topk_trace + 8 : nullptr;
+  fp.wgtrace = g_wg_trace;
   {
     ProfScope ps(PKV_K_FINALIZE, st);
     hipError_t e = launch_finalize(d->dtype, fp, st);
@@ -165,11 +169,11 @@ int do_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores, 
 }
 
 int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t stride, const int32_t* kpr,
-            int32_t* idx, int64_t idx_stride, hipStream_t st) {
+            int32_t* idx, int64_t idx_stride, hipStream_t st, const void* cmax = nullptr, int64_t cmax_stride = 0) {
   if (L < 1 || k < 1 || k > L || rows < 1) return PKV_ERR_SHAPE;
   TopkParams tp;
   tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
-  tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace;
+  tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace; tp.wgtrace = g_wg_trace; tp.cmax = cmax; tp.cmax_stride = cmax_stride;
   const size_t lds = topk_lds_bytes(L, k, &tp.Lw, &tp.kpad);
   if (lds > 160 * 1024 || 16 * (size_t)tp.Lw > 65536) return PKV_ERR_UNSUPPORTED;
   {
@@ -184,7 +188,7 @@ int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t strid
 GatherParams make_gather(const pkv_desc* d, const void* k, const void* v, void* ko, void* vo) {
   GatherParams g;
   g.kptr = k; g.vptr = v; g.k_out = ko; g.v_out = vo;
-  g.idx = nullptr; g.idx_stride = 0; g.head_k = nullptr; g.cu_rows = nullptr;
+  g.idx = nullptr; g.idx_stride = 0; g.head_k = nullptr; g.cu_rows = nullptr; g.wgtrace = g_wg_trace;
   g.B = d->B; g.H = d->H; g.S = d->S; g.w = d->window; g.nsel = d->topk; g.G = d->kv_group;
   g.ks_b = d->k_stride[0]; g.ks_h = d->k_stride[1]; g.ks_s = d->k_stride[2];
   g.vs_b = d->v_stride[0]; g.vs_h = d->v_stride[1]; g.vs_s = d->v_stride[2];
@@ -209,10 +213,12 @@ int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* w = static_cast<char*>(ws);
   void* scores = w + L.off_scores;
-  rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st);
+  const bool cm = !h2o && env_int("PKV_TOPK_CMAX", 1) != 0;   // chunk maxima feed the top-k prefilter
+  rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
   int32_t* idx = idx_out ? idx_out : reinterpret_cast<int32_t*>(w + L.off_idx);
-  rc = do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx, d->topk, st);
+  rc = do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx, d->topk, st,
+               cm ? w + L.off_cmax : nullptr, L.Lp / 8);
   if (rc) return rc;
   GatherParams g = make_gather(d, k, v, k_out, v_out);
   g.idx = idx; g.idx_stride = d->topk;
@@ -382,6 +388,8 @@ int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const vo
 
 /* ---- debug / test hooks (not part of the drop-in surface) ---- */
 int pkv_debug_topk_trace(void* device_u64x8) { g_topk_trace = static_cast<unsigned long long*>(device_u64x8); return PKV_OK; }
+
+int pkv_debug_wg_trace(void* device_u64) { g_wg_trace = static_cast<unsigned long long*>(device_u64); return PKV_OK; }
 
 int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream) {
   hipError_t e = launch_debug_exp(in, out, n, static_cast<hipStream_t>(stream));

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
   const int nrows = nsel + p.w;
   const int r_blk = blockIdx.x * GA_ROWS;
   if (r_blk >= nrows) return;
+  const unsigned long long t_start = p.wgtrace ? wall_clock64() : 0ull;
   const int64_t out_row0 = p.cu_rows ? (int64_t)p.cu_rows[bh] : (int64_t)bh * nrows;
 
   const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h + chunk * 8;
@@ -73,6 +74,10 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
       __builtin_nontemporal_store(kd[j], reinterpret_cast<u32x4*>(ko + orow * 128));
       __builtin_nontemporal_store(vd[j], reinterpret_cast<u32x4*>(vo + orow * 128));
     }
+  }
+  if (p.wgtrace && tid == 0) {
+    const size_t wg = 196608 + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 262144) { p.wgtrace[2 * wg] = t_start; p.wgtrace[2 * wg + 1] = wall_clock64(); }
   }
 }
 

@@ -6,6 +6,7 @@
 namespace pkv {
 
 struct LogitsParams {
+  unsigned long long* wgtrace;   // debug: per-workgroup (start,end) wall clock, may be null
   const void* q;
   const void* k;
   void* logits;      // [B*H*w][Sp] model dtype
@@ -28,7 +29,10 @@ struct FinalizeParams {
   int64_t scores_stride;
   int B, H, S, w, Sp, nT;
   int pool_kind, pool_kernel, reduce;
+  void* cmax;            // [B*H][cmax_stride] max pooled score of every 8-position chunk (may be null)
+  int64_t cmax_stride;
   unsigned long long* trace;   // debug: phase timestamps of block (0,0) (may be null)
+  unsigned long long* wgtrace;
 };
 
 struct TopkParams {
@@ -36,9 +40,12 @@ struct TopkParams {
   int64_t scores_stride;
   int L, k;
   const int32_t* k_per_row;
+  const void* cmax;      // optional: per-chunk (8 scores) maxima written by finalize_kernel, [rows][cmax_stride]
+  int64_t cmax_stride;
   int32_t* idx_out;      // [rows][idx_stride]
   int64_t idx_stride;
   unsigned long long* trace;   // debug: phase timestamps of row 0 (may be null)
+  unsigned long long* wgtrace;
   int Lw;                // keys per wave (multiple of 512)
   int kpad;              // words reserved for the selection list (see topk_lds_bytes)
   int dual;              // second 32 KB counter / radix scratch region present in LDS
@@ -53,6 +60,7 @@ struct SortParams {
 };
 
 struct GatherParams {
+  unsigned long long* wgtrace;   // debug: per-workgroup (start,end) wall clock, may be null
   const void* kptr;
   const void* vptr;
   void* k_out;

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   const int S = p.S;
   const int L = S - w;
 
+  const unsigned long long t_start = p.wgtrace ? wall_clock64() : 0ull;
   const int li = lane & 15;   // key within 16-subtile (A rows) / column within 16-tile (B cols)
   const int lg = lane >> 4;   // 8-element d-chunk within a 32-wide k-step
 
@@ -173,6 +174,10 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
     if (chunk == 0) p.partial[(rowbase + row) * p.nT + t_idx] = make_float2(m, l);
     *reinterpret_cast<uint4*>(lg_out + (rowbase + row) * (int64_t)p.Sp + s0) = u.v;
   }
+  if (p.wgtrace && tid == 0) {
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    p.wgtrace[2 * wg] = t_start; p.wgtrace[2 * wg + 1] = wall_clock64();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   const int64_t rowbase = (int64_t)bh * w;
 #define PKV_FSTAMP(i) do { if (p.trace && tid == 0 && blockIdx.x == 1 && bh == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
   PKV_FSTAMP(0);
+  const unsigned long long t_start = p.wgtrace ? wall_clock64() : 0ull;
 
   // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M).
   // 32 lanes per row, 8 rows per pass; every lane issues its (<= 8 per chunk) partial loads back to
@@ -245,23 +251,26 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const uint16_t* lgp = reinterpret_cast<const uint16_t*>(p.logits) + rowbase * (int64_t)p.Sp + s0;
     for (int rb = 0; rb < w; rb += 8) {
+      // 8 rows per pass, all loads first.  Rows past w are clamped (re-read row w-1) and weighted 0:
+      // no control flow between the loads and their uses, so they stay batched (one round trip).
       uint2 u[8];
+      float M[8], RZ[8], wt[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = rb + j < w ? rb + j : w - 1;
         u[j] = *reinterpret_cast<const uint2*>(lgp + (int64_t)r * p.Sp);
+        M[j] = rowM[r];
+        RZ[j] = rowS[r];
+        wt[j] = rb + j < w ? 1.0f : 0.0f;
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (rb + j < w) {
-          const float M = rowM[rb + j], RZ = rowS[rb + j];
-          const uint16_t h4[4] = {(uint16_t)(u[j].x & 0xffffu), (uint16_t)(u[j].x >> 16),
-                                  (uint16_t)(u[j].y & 0xffffu), (uint16_t)(u[j].y >> 16)};
+        const uint16_t h4[4] = {(uint16_t)(u[j].x & 0xffffu), (uint16_t)(u[j].x >> 16),
+                                (uint16_t)(u[j].y & 0xffffu), (uint16_t)(u[j].y >> 16)};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float pr = pkv_exp(Elem<T>::to_f32(h4[e]) - M) * RZ;            // fp32 softmax (:326)
-            acc[e] += Elem<T>::to_f32(Elem<T>::from_f32(pr));                     // .to(dtype); fp32 row accumulate (:327)
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float pr = pkv_exp(Elem<T>::to_f32(h4[e]) - M[j]) * RZ[j];        // fp32 softmax (:326)
+          acc[e] += wt[j] * Elem<T>::to_f32(Elem<T>::from_f32(pr));               // .to(dtype); fp32 row accumulate (:327)
         }
       }
     }
@@ -282,10 +291,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   __syncthreads();
   PKV_FSTAMP(3);
 
-  if (tid < 2 || tid >= 254 || s0 >= L) return;   // halo threads / nothing to write
+  if (p.wgtrace && tid == 0) {
+    const size_t wg = 65536 + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    p.wgtrace[2 * wg] = t_start; p.wgtrace[2 * wg + 1] = wall_clock64();
+  }
+  const bool writer = !(tid < 2 || tid >= 254 || s0 >= L);   // halo threads / positions past the row write nothing
   uint16_t res[4];
   const int half = p.pool_kernel >> 1;
-  if (p.pool_kind == 0) {
+  if (p.pool_kind == 0 || !writer) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) res[e] = ov[e];
   } else {
@@ -320,6 +333,23 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
       }
     }
   }
+  // per-chunk maxima (8 consecutive positions = an even/odd lane pair) for the top-k prefilter
+  if (p.cmax) {
+    float m4 = -INFINITY;
+    uint16_t b4 = Elem<T>::neg_inf();
+    if (writer) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = Elem<T>::to_f32(res[e]);
+        if (s0 + e < L && x > m4) { m4 = x; b4 = res[e]; }
+      }
+    }
+    const float mo = __shfl_xor(m4, 1, 64);
+    const uint32_t bo = __shfl_xor((uint32_t)b4, 1, 64);
+    if (writer && !(tid & 1))
+      reinterpret_cast<uint16_t*>(p.cmax)[(int64_t)bh * p.cmax_stride + (s0 >> 3)] = (mo > m4) ? (uint16_t)bo : b4;
+  }
+  if (!writer) return;
   uint2 ro;
   ro.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
   ro.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);

@@ -21,6 +21,8 @@ constexpr int TK_WAVES = 16;
 constexpr int TK_CNT_WORDS = 256 * 32;   // counters[bin][lane&31], lo16 = lanes 0-31, hi16 = lanes 32-63
 constexpr int TK_RANK_MAX = 512;         // k <= this: order by rank counting (O(k^2), no barriers)
 constexpr int TK_RADIX_MAX = 4096;       // k <= this (and LDS allows): stable 2-pass LSD radix ordering
+constexpr int TK_FAST_K = 512;           // k <= this: try the chunk-maxima prefilter first
+constexpr int TK_FAST_C = 1024;          // prefilter succeeds if at most this many keys pass it
 constexpr size_t TK_LDS_LIMIT = 160 * 1024;
 
 // LDS layout: keys u16[16*Lw] | X u32[max(8192,kpad)] | hist u32[256] | misc u32[64] | X2 u32[8192] (if it fits)
@@ -29,7 +31,7 @@ size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out) {
   int Lw = ((per_wave + 511) / 512) * 512;
   if (Lw < 512) Lw = 512;
   int kpad;
-  if (k <= TK_RADIX_MAX) kpad = (k + 3) & ~3;
+  if (k <= TK_RADIX_MAX) kpad = (k + 15) & ~15;
   else { kpad = 1; while (kpad < k) kpad <<= 1; }
   if (Lw_out) *Lw_out = Lw;
   if (kpad_out) *kpad_out = kpad;
@@ -39,40 +41,41 @@ size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out) {
   return base;
 }
 
-// sum the bank-spread counters into hist[256]
+// sum the bank-spread counters X[bin][32] (lo16/hi16 halves) into hist[256]; all 1024 threads, 4 per bin
 __device__ __forceinline__ void reduce_counters(const uint32_t* X, uint32_t* hist, int tid) {
   const int bin = tid >> 2, part = tid & 3;
-  uint32_t s = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint32_t v = X[bin * 32 + part * 8 + i];
-    s += (v & 0xffffu) + (v >> 16);
-  }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
+  const uint4* r4 = reinterpret_cast<const uint4*>(X + bin * 32 + part * 8);
+  const uint4 a = r4[0], b = r4[1];
+  uint32_t s = (a.x & 0xffffu) + (a.x >> 16) + (a.y & 0xffffu) + (a.y >> 16) + (a.z & 0xffffu) + (a.z >> 16) +
+               (a.w & 0xffffu) + (a.w >> 16) + (b.x & 0xffffu) + (b.x >> 16) + (b.y & 0xffffu) + (b.y >> 16) +
+               (b.z & 0xffffu) + (b.z >> 16) + (b.w & 0xffffu) + (b.w >> 16);
+  s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0xb1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x4e, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
   if (part == 0) hist[bin] = s;
 }
 
-// bin b with  above(b) < need <= above(b) + hist[b]  where above(b) = sum_{b'>b} hist[b'].
-// One wavefront: lane l owns bins 4l..4l+3; suffix sums across lanes by shuffles.
+// bin b with  above(b) < need <= above(b) + hist[b],  above(b) = sum_{b' > b} hist[b'].
+// One wavefront: lane l owns bins 4l..4l+3; suffix sums from a DPP prefix scan.
 __device__ __forceinline__ void find_bin(const uint32_t* hist, uint32_t need, int* out_bin, int* out_above, int tid) {
   if (tid < 64) {
     const uint4 h = reinterpret_cast<const uint4*>(hist)[tid];
-    const uint32_t own = h.x + h.y + h.z + h.w;
-    uint32_t incl = own;                       // inclusive suffix sum over lanes >= tid
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_down(incl, o, 64);
-      if (tid + o < 64) incl += t;
-    }
-    uint32_t above = incl - own;               // bins of higher lanes
     const uint32_t hv[4] = {h.x, h.y, h.z, h.w};
+    const uint32_t own = h.x + h.y + h.z + h.w;
+    const uint32_t incl = wave_incl_scan_u32(own);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t above = total - incl;               // bins of higher lanes
 #pragma unroll
     for (int i = 3; i >= 0; --i) {
       if (above < need && need <= above + hv[i]) { *out_bin = tid * 4 + i; *out_above = (int)above; }
       above += hv[i];
     }
   }
+}
+
+__device__ __forceinline__ void select_bin(const uint32_t* X, uint32_t* hist, uint32_t need, int* out_bin, int* out_above, int tid) {
+  reduce_counters(X, hist, tid);
+  __syncthreads();
+  find_bin(hist, need, out_bin, out_above, tid);
 }
 
 // One stable LSD radix pass over k composites (key<<16 | ~idx) by descending key byte `byte` (0/1).
@@ -170,44 +173,228 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
 
 #define PKV_STAMP(i) do { if (p.trace && tid == 0 && row == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
   PKV_STAMP(0);
+  const unsigned long long t_start = p.wgtrace ? wall_clock64() : 0ull;
   // ---- pass A: HBM/L2 -> ordered keys in LDS, histogram of the high byte.  All (<= 8) 16-B loads of a
   //      lane are issued first; the counter arrays are zeroed while they are in flight. ----
+  const int nch = (L + 7) >> 3;                                   // 8-key chunks in the row
+  const bool fast_ok = k <= TK_FAST_K && 2 * k <= nch;            // prefilter applicable (see below)
+  const bool use_cmax = fast_ok && p.cmax != nullptr && vec_ok;   // chunk maxima precomputed by finalize_kernel
   U4 raw[8];
+  uint16_t cm[8];
+  auto load_all = [&]() {
+    if (vec_ok) {
+      // stride % 8 == 0 and stride >= L  =>  stride >= roundup(L, 8): the 16-B load of the last, partial
+      // chunk stays inside the row; out-of-range lanes re-read the row start and are masked below.
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j < niter) {
-      const int base = wave * Lw + j * 512 + lane * 8;
-      if (vec_ok && base + 8 <= L) {
-        raw[j].v = *reinterpret_cast<const uint4*>(src + base);
-      } else {
+      for (int j = 0; j < 8; ++j) {
+        if (j < niter) {
+          const int base = wave * Lw + j * 512 + lane * 8;
+          raw[j].v = *reinterpret_cast<const uint4*>(src + (base < L ? base : 0));
+        }
+      }
+    } else {
+      // unaligned rows (external callers only): unconditional clamped 2-byte loads, masked below
 #pragma unroll
-        for (int e = 0; e < 8; ++e) raw[j].h[e] = (base + e < L) ? src[base + e] : (uint16_t)0;
+      for (int j = 0; j < 8; ++j) {
+        if (j < niter) {
+          const int base = wave * Lw + j * 512 + lane * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) raw[j].h[e] = src[base + e < L ? base + e : L - 1];
+        }
       }
     }
+  };
+  if (use_cmax) {
+    const uint16_t* cmp = reinterpret_cast<const uint16_t*>(p.cmax) + (int64_t)row * p.cmax_stride;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < niter) {
+        const int c = wave * (Lw >> 3) + j * 64 + lane;             // chunk (j, lane) of this wave
+        cm[j] = cmp[c < nch ? c : 0];
+      }
+    }
+  } else {
+    load_all();
   }
   for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
   __syncthreads();
   if (p.trace && tid == 0 && row == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[7] = (unsigned long long)clock64(); }
+  U4 kreg[8];     // this lane's ordered keys (niter chunks of 8), kept in registers for every later pass
+  auto transform_all = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < niter) {
+        const int base = wave * Lw + j * 512 + lane * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kreg[j].w[q] = order_key_pk<T>(raw[j].w[q]);
+        if (base + 8 > L) {                       // partial or out-of-range chunk: padding keys are 0
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (base + e >= L) kreg[j].h[e] = 0;
+        }
+        *reinterpret_cast<uint4*>(keys + base) = kreg[j].v;
+      }
+    }
+  };
+  if (!use_cmax) transform_all();
+
+  // ---- fast path (small k): the k-th largest of the per-chunk maxima is a lower bound x* of the
+  //      selection threshold (at least k keys are >= x*), and usually only a few hundred keys pass it.
+  //      Select x* from 1024*niter chunk maxima (<= 8 LDS atomics per lane instead of 8*niter*... per
+  //      key), compact the candidates in index order, and rank them by counting: rank < k <=> selected,
+  //      and the rank IS the output position.  Falls back to the full radix select when too many
+  //      keys tie at or above x*. ----
+  if (fast_ok) {
+    uint32_t gm[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < niter) {
+        uint32_t m = 0;
+        if (use_cmax) {
+          const int c = wave * (Lw >> 3) + j * 64 + lane;
+          m = c < nch ? order_key<T>(cm[j]) : 0u;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) m = m > kreg[j].h[e] ? m : (uint32_t)kreg[j].h[e];
+        }
+        gm[j] = m;
+        atomicAdd(&X[(m >> 8) * 32 + cslot], inc);
+      }
+    }
+    __syncthreads();
+    select_bin(X, hist, (uint32_t)k, &misc[0], &misc[1], tid);
+    __syncthreads();
+    PKV_STAMP(1);
+    const uint32_t fb1 = (uint32_t)misc[0];
+    const int fabove = misc[1];
+    uint32_t* XF = dual ? X2 : X;
+    if (!dual) {
+      for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X[i] = 0;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < niter && (gm[j] >> 8) == fb1) atomicAdd(&XF[(gm[j] & 255u) * 32 + cslot], inc);
+    __syncthreads();
+    select_bin(XF, hist, (uint32_t)(k - fabove), &misc[2], &misc[3], tid);
+    __syncthreads();
+    PKV_STAMP(2);
+    const uint32_t xstar = (fb1 << 8) | (uint32_t)misc[2];
+    if (use_cmax) {
+      // only chunks whose maximum reaches x* can hold candidates: fetch just those (16 B each)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < niter) {
+          const int base = wave * Lw + j * 512 + lane * 8;
+          raw[j].v = make_uint4(0, 0, 0, 0);
+          if (gm[j] >= xstar) raw[j].v = *reinterpret_cast<const uint4*>(src + base);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < niter) {
+          const int base = wave * Lw + j * 512 + lane * 8;
+          kreg[j].v = make_uint4(0, 0, 0, 0);
+          if (gm[j] >= xstar) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kreg[j].w[q] = order_key_pk<T>(raw[j].w[q]);
+            if (base + 8 > L) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (base + e >= L) kreg[j].h[e] = 0;
+            }
+          }
+        }
+      }
+    }
+    uint32_t cl = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < niter) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cl += kreg[j].h[e] >= xstar;
+      }
+    const uint32_t cw = wave_sum_u32(cl);
+    if (lane == 0) wcnt[wave] = cw;
+    __syncthreads();
+    uint32_t C = 0, cbase = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < TK_WAVES; ++w2) { const uint32_t c = wcnt[w2]; C += c; cbase += (w2 < wave) ? c : 0u; }
+    PKV_STAMP(3);
+    if (p.trace && tid == 0 && row == 0) p.trace[15] = C;
+    if (C <= TK_FAST_C) {
+      uint32_t* cand = X;                       // the stage-1 counters in X are no longer needed
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < niter) {
+          uint32_t cj = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cj += kreg[j].h[e] >= xstar;
+          if (__ballot(cj != 0) == 0ull) continue;
+          const uint32_t incl = wave_incl_scan_u32(cj);
+          uint32_t pos = cbase + incl - cj;
+          const int base = wave * Lw + j * 512 + lane * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t key = kreg[j].h[e];
+            if (key >= xstar) cand[pos++] = (key << 16) | (0xffffu - (uint32_t)(base + e));
+          }
+          cbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+      }
+      // rank = number of candidates with a larger composite.  All 1024 threads take part: a candidate is
+      // shared by G = 1024 / pow2(C) adjacent lanes, each scanning every G-th block of 32 composites
+      // (8 independent 16-B broadcast reads per step), partial ranks summed with lane shuffles.
+      int Cp = 64;
+      while (Cp < (int)C) Cp <<= 1;
+      const int G = (TK_THREADS / Cp) > 4 ? 4 : (TK_THREADS / Cp);   // 1..4 (more lanes per candidate only adds bank conflicts)
+      const int blocks = (((int)C + 31) >> 5);
+      const int steps = (blocks + G - 1) / G;
+      const int cpad = steps * G * 32;                      // <= 1024 + 512 words, inside X (8192 words)
+      for (int i = (int)C + tid; i < cpad; i += TK_THREADS) cand[i] = 0;
+      __syncthreads();
+      PKV_STAMP(5);
+      {
+        const int ci = tid / G, g = tid - ci * G;
+        const uint32_t mine = ci < (int)C ? cand[ci] : 0xffffffffu;
+        int rank = 0;
+        const uint4* c4 = reinterpret_cast<const uint4*>(cand);
+        for (int it = 0; it < steps; ++it) {
+          const uint4* blk = c4 + (it * G + g) * 8;
+          uint4 a[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a[q] = blk[q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rank += (a[q].x > mine) + (a[q].y > mine) + (a[q].z > mine) + (a[q].w > mine);
+        }
+        for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
+        if (g == 0 && ci < (int)C && rank < k)
+          p.idx_out[(int64_t)row * p.idx_stride + rank] = (int32_t)(0xffffu - (mine & 0xffffu));
+      }
+      PKV_STAMP(6);
+      if (p.wgtrace && tid == 0) { p.wgtrace[2 * (131072 + row)] = t_start; p.wgtrace[2 * (131072 + row) + 1] = wall_clock64(); }
+      return;
+    }
+    // too many keys at or above x* (heavy ties): full path.  Its counters must start from zero.
+    if (use_cmax) { load_all(); transform_all(); }
+    __syncthreads();
+    for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
+    __syncthreads();
+  }
+
+  // ---- full path, pass A: histogram of the high byte (one LDS atomic per key: ~16 cycles per
+  //      wave-instruction whatever the number of active lanes) ----
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (j < niter) {
-      const int base = wave * Lw + j * 512 + lane * 8;
-      U4 ko;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const bool valid = base + e < L;
-        const uint32_t key = valid ? order_key<T>(raw[j].h[e]) : 0u;
-        ko.h[e] = (uint16_t)key;
-        if (valid) atomicAdd(&X[(key >> 8) * 32 + cslot], inc);   // ~16 cycles per wave-instruction, any lane count
+        const uint32_t key = kreg[j].h[e];
+        if (key != 0u) atomicAdd(&X[(key >> 8) * 32 + cslot], inc);
       }
-      *reinterpret_cast<uint4*>(keys + base) = ko.v;
     }
   }
   __syncthreads();
   PKV_STAMP(1);
-  reduce_counters(X, hist, tid);
-  __syncthreads();
-  find_bin(hist, (uint32_t)k, &misc[0], &misc[1], tid);
+  select_bin(X, hist, (uint32_t)k, &misc[0], &misc[1], tid);
   __syncthreads();
   PKV_STAMP(2);
   const uint32_t b1 = (uint32_t)misc[0];
@@ -230,9 +417,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     }
   }
   __syncthreads();
-  reduce_counters(XB, hist, tid);
-  __syncthreads();
-  find_bin(hist, (uint32_t)(k - n_above1), &misc[2], &misc[3], tid);
+  select_bin(XB, hist, (uint32_t)(k - n_above1), &misc[2], &misc[3], tid);
   __syncthreads();
   PKV_STAMP(3);
   const uint32_t Tkey = (b1 << 8) | (uint32_t)misc[2];
@@ -295,12 +480,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         }
       }
     }
-    const uint32_t tot = __shfl(incl, 63, 64);
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     run_g += tot & 0xffffu;
     run_e += tot >> 16;
   }
   int kpad;
-  if (k <= TK_RADIX_MAX) kpad = (k + 3) & ~3;
+  if (k <= TK_RADIX_MAX) kpad = (k + 15) & ~15;
   else { kpad = 1; while (kpad < k) kpad <<= 1; }
   for (int i = k + tid; i < kpad; i += TK_THREADS) sel[i] = 0;   // padding: composite 0 sorts last, never emitted
   __syncthreads();
@@ -313,9 +498,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       const uint32_t mine = sel[tid];
       int rank = 0;
       const uint4* s4 = reinterpret_cast<const uint4*>(sel);
-      for (int j = 0; j < (kpad >> 2); ++j) {
-        const uint4 c = s4[j];   // same address for every lane: LDS broadcast
-        rank += (c.x > mine) + (c.y > mine) + (c.z > mine) + (c.w > mine);
+      for (int j = 0; j < (kpad >> 4); ++j) {   // kpad is a multiple of 16 here; same address for every lane: LDS broadcast
+        const uint4 a0 = s4[4 * j], a1 = s4[4 * j + 1], a2 = s4[4 * j + 2], a3 = s4[4 * j + 3];
+        rank += (a0.x > mine) + (a0.y > mine) + (a0.z > mine) + (a0.w > mine) + (a1.x > mine) + (a1.y > mine) +
+                (a1.z > mine) + (a1.w > mine) + (a2.x > mine) + (a2.y > mine) + (a2.z > mine) + (a2.w > mine) +
+                (a3.x > mine) + (a3.y > mine) + (a3.z > mine) + (a3.w > mine);
       }
       out[rank] = (int32_t)(0xffffu - (mine & 0xffffu));
     }
@@ -349,6 +536,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     for (int i = tid; i < k; i += TK_THREADS) out[i] = (int32_t)(0xffffu - (sel[i] & 0xffffu));
   }
   PKV_STAMP(6);
+  if (p.wgtrace && tid == 0) { p.wgtrace[2 * (131072 + row)] = t_start; p.wgtrace[2 * (131072 + row) + 1] = wall_clock64(); }
 #undef PKV_STAMP
 }
 

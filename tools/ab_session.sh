@@ -8,6 +8,6 @@ cd $R
 timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.txt 2>&1
 echo "pytest exit $?" >> $O/pytest.txt
 python tools/topk_trace.py > $O/topk_trace.json 2> $O/topk_trace.err
-timeout 600 python tools/sweep.py quick > $O/sweep_quick.json 2> $O/sweep_quick.err
+python tools/wg_trace.py > $O/wg_trace.json 2> $O/wg_trace.err
 timeout 900 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
-tail -4 $O/pytest.txt; cat $O/topk_trace.json
+tail -4 $O/pytest.txt
