@@ -5,9 +5,5 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.txt 2>&1
-echo "pytest exit $?" >> $O/pytest.txt
-python tools/topk_trace.py > $O/topk_trace.json 2> $O/topk_trace.err
-python tools/wg_trace.py > $O/wg_trace.json 2> $O/wg_trace.err
-timeout 900 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
-tail -4 $O/pytest.txt
+timeout 900 python tools/policy_bench.py > $O/policy_bench.json 2> $O/policy_bench.err
+cat $O/policy_bench.json; tail -3 $O/policy_bench.err
