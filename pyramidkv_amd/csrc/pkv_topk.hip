@@ -22,7 +22,8 @@ constexpr int TK_CNT_WORDS = 256 * 32;   // counters[bin][lane&31], lo16 = lanes
 constexpr int TK_RANK_MAX = 512;         // k <= this: order by rank counting (O(k^2), no barriers)
 constexpr int TK_RADIX_MAX = 4096;       // k <= this (and LDS allows): stable 2-pass LSD radix ordering
 constexpr int TK_FAST_K = 512;           // k <= this: try the chunk-maxima prefilter first
-constexpr int TK_FAST_C = 1024;          // prefilter succeeds if at most this many keys pass it
+constexpr int TK_FAST_C = 384;           // at most this many candidates: rank them directly (O(C^2))
+constexpr int TK_MID_C = 4096;           // at most this many: exact select inside the candidate list first
 constexpr size_t TK_LDS_LIMIT = 160 * 1024;
 
 // LDS layout: keys u16[16*Lw] | X u32[max(8192,kpad)] | hist u32[256] | misc u32[64] | X2 u32[8192] (if it fits)
@@ -320,7 +321,35 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     for (int w2 = 0; w2 < TK_WAVES; ++w2) { const uint32_t c = wcnt[w2]; C += c; cbase += (w2 < wave) ? c : 0u; }
     PKV_STAMP(3);
     if (p.trace && tid == 0 && row == 0) p.trace[15] = C;
-    if (C <= TK_FAST_C) {
+    // rank = number of list entries with a larger composite; entries with rank < k are the selection and
+    // the rank is the output position.  All 1024 threads take part: an entry is shared by G <= 4 adjacent
+    // lanes, each scanning every G-th block of 32 composites (8 independent 16-B broadcast reads per step).
+    auto rank_store = [&](uint32_t* list, int n) {
+      int Cp = 64;
+      while (Cp < n) Cp <<= 1;
+      const int G = (TK_THREADS / Cp) > 4 ? 4 : (TK_THREADS / Cp);
+      const int blocks = (n + 31) >> 5;
+      const int steps = (blocks + G - 1) / G;
+      const int cpad = steps * G * 32;
+      for (int i = n + tid; i < cpad; i += TK_THREADS) list[i] = 0;
+      __syncthreads();
+      const int ci = tid / G, g = tid - ci * G;
+      const uint32_t mine = ci < n ? list[ci] : 0xffffffffu;
+      int rank = 0;
+      const uint4* c4 = reinterpret_cast<const uint4*>(list);
+      for (int it = 0; it < steps; ++it) {
+        const uint4* blk = c4 + (it * G + g) * 8;
+        uint4 a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = blk[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rank += (a[q].x > mine) + (a[q].y > mine) + (a[q].z > mine) + (a[q].w > mine);
+      }
+      for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
+      if (g == 0 && ci < n && rank < k)
+        p.idx_out[(int64_t)row * p.idx_stride + rank] = (int32_t)(0xffffu - (mine & 0xffffu));
+    };
+    if (C <= TK_FAST_C || (C <= TK_MID_C && dual)) {
       uint32_t* cand = X;                       // the stage-1 counters in X are no longer needed
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -340,34 +369,66 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
           cbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
       }
-      // rank = number of candidates with a larger composite.  All 1024 threads take part: a candidate is
-      // shared by G = 1024 / pow2(C) adjacent lanes, each scanning every G-th block of 32 composites
-      // (8 independent 16-B broadcast reads per step), partial ranks summed with lane shuffles.
-      int Cp = 64;
-      while (Cp < (int)C) Cp <<= 1;
-      const int G = (TK_THREADS / Cp) > 4 ? 4 : (TK_THREADS / Cp);   // 1..4 (more lanes per candidate only adds bank conflicts)
-      const int blocks = (((int)C + 31) >> 5);
-      const int steps = (blocks + G - 1) / G;
-      const int cpad = steps * G * 32;                      // <= 1024 + 512 words, inside X (8192 words)
-      for (int i = (int)C + tid; i < cpad; i += TK_THREADS) cand[i] = 0;
-      __syncthreads();
-      PKV_STAMP(5);
-      {
-        const int ci = tid / G, g = tid - ci * G;
-        const uint32_t mine = ci < (int)C ? cand[ci] : 0xffffffffu;
-        int rank = 0;
-        const uint4* c4 = reinterpret_cast<const uint4*>(cand);
-        for (int it = 0; it < steps; ++it) {
-          const uint4* blk = c4 + (it * G + g) * 8;
-          uint4 a[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) a[q] = blk[q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) rank += (a[q].x > mine) + (a[q].y > mine) + (a[q].z > mine) + (a[q].w > mine);
+      if (C <= TK_FAST_C) {
+        PKV_STAMP(5);
+        rank_store(cand, (int)C);
+      } else {
+        // 1024 < C <= 4096 candidates: exact radix select INSIDE the candidate list (<= 4 keys per thread
+        // and pass), index-ordered compaction of the k winners, then rank them.
+        __syncthreads();                                        // candidate list complete
+        for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X2[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < (int)C; i += TK_THREADS) atomicAdd(&X2[(cand[i] >> 24) * 32 + cslot], inc);
+        __syncthreads();
+        select_bin(X2, hist, (uint32_t)k, &misc[4], &misc[5], tid);
+        __syncthreads();
+        const uint32_t mb1 = (uint32_t)misc[4];
+        const int mabove = misc[5];
+        for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X2[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < (int)C; i += TK_THREADS) {
+          const uint32_t key = cand[i] >> 16;
+          if ((key >> 8) == mb1) atomicAdd(&X2[(key & 255u) * 32 + cslot], inc);
         }
-        for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
-        if (g == 0 && ci < (int)C && rank < k)
-          p.idx_out[(int64_t)row * p.idx_stride + rank] = (int32_t)(0xffffu - (mine & 0xffffu));
+        __syncthreads();
+        select_bin(X2, hist, (uint32_t)(k - mabove), &misc[6], &misc[7], tid);
+        __syncthreads();
+        const uint32_t Tm = (mb1 << 8) | (uint32_t)misc[6];
+        const int m_gt = mabove + misc[7];
+        const int m_eq_take = k - m_gt;
+        // thread t owns cand[4t .. 4t+4): list order == index order, so a block-wide exclusive scan of the
+        // per-thread (gt, eq) counts gives index-ordered output slots
+        uint32_t ck[4];
+        uint32_t cg = 0, ce = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = tid * 4 + e;
+          ck[e] = i < (int)C ? cand[i] : 0u;
+          const uint32_t key = ck[e] >> 16;
+          cg += (i < (int)C) && key > Tm;
+          ce += (i < (int)C) && key == Tm;
+        }
+        const uint32_t packed = (ce << 16) | cg;
+        const uint32_t incl = wave_incl_scan_u32(packed);
+        if (lane == 63) wcnt[wave] = incl;
+        __syncthreads();
+        uint32_t basep = 0;
+        for (int w2 = 0; w2 < wave; ++w2) basep += wcnt[w2];
+        uint32_t og = (basep & 0xffffu) + ((incl - packed) & 0xffffu);
+        uint32_t oe = (basep >> 16) + ((incl - packed) >> 16);
+        uint32_t* sel2 = X + TK_MID_C;                          // second half of X (cand uses the first 4096 words)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = tid * 4 + e;
+          if (i < (int)C) {
+            const uint32_t key = ck[e] >> 16;
+            if (key > Tm) sel2[og++] = ck[e];
+            else if (key == Tm) { if ((int)oe < m_eq_take) sel2[m_gt + oe] = ck[e]; ++oe; }
+          }
+        }
+        __syncthreads();
+        PKV_STAMP(5);
+        rank_store(sel2, k);
       }
       PKV_STAMP(6);
       if (p.wgtrace && tid == 0) { p.wgtrace[2 * (131072 + row)] = t_start; p.wgtrace[2 * (131072 + row) + 1] = wall_clock64(); }
