@@ -40,12 +40,22 @@ __device__ __forceinline__ int count_ge(const uint16_t* v, int L, float ratio, i
   return lo;
 }
 
+// the head's sorted scores (<= 64 KB) are staged in LDS: the 256 binary searches then cost ~15 LDS
+// round trips instead of 15 global-memory round trips
+__device__ __forceinline__ const uint16_t* stage_row(const uint16_t* g, int L, uint16_t* lds, int tid) {
+  for (int i = tid; i < L; i += 256) lds[i] = g[i];
+  __syncthreads();
+  return lds;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ada_stats_kernel(BudgetParams p, AdaWs ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ada_smem[];
   __shared__ double red[2][4];
   __shared__ float s_ratio;
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint16_t* v = reinterpret_cast<const uint16_t*>(p.sorted_val) + (int64_t)h * p.L;
+  const uint16_t* v = stage_row(reinterpret_cast<const uint16_t*>(p.sorted_val) + (int64_t)h * p.L, p.L,
+                                reinterpret_cast<uint16_t*>(ada_smem), tid);
   float ratio = 1.0f;
   if (p.normalize) {
     double st = 0.0, sa = 0.0;
@@ -86,12 +96,14 @@ __device__ __forceinline__ int find_level(const int32_t* cum, int H, int64_t tot
 
 template <typename T>
 __global__ __launch_bounds__(256) void ada_lo_kernel(BudgetParams p, AdaWs ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ada_smem[];
   __shared__ int64_t s_sum[256];
   __shared__ int s_b;
   const int h = blockIdx.x, tid = threadIdx.x;
   const int64_t total = (int64_t)p.H * p.base;
+  const uint16_t* v = stage_row(reinterpret_cast<const uint16_t*>(p.sorted_val) + (int64_t)h * p.L, p.L,
+                                reinterpret_cast<uint16_t*>(ada_smem), tid);
   const int b1 = find_level(ws.cum_hi, p.H, total, s_sum, &s_b, tid);
-  const uint16_t* v = reinterpret_cast<const uint16_t*>(p.sorted_val) + (int64_t)h * p.L;
   ws.cum_lo[h * 256 + tid] = count_ge<T>(v, p.L, ws.ratio[h], p.normalize, ((uint32_t)b1 << 8) | (uint32_t)tid);
 }
 
@@ -141,13 +153,16 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st) {
   ws.cum_hi = reinterpret_cast<int32_t*>(base + 1024);
   ws.cum_lo = ws.cum_hi + (size_t)p.H * 256;
   const float omf = p.one_minus_floor;
-  if (dtype == 0) {
-    hipLaunchKernelGGL(ada_stats_kernel<BF16>, dim3(p.H), dim3(256), 0, st, p, ws);
-    hipLaunchKernelGGL(ada_lo_kernel<BF16>, dim3(p.H), dim3(256), 0, st, p, ws);
-  } else {
-    hipLaunchKernelGGL(ada_stats_kernel<F16>, dim3(p.H), dim3(256), 0, st, p, ws);
-    hipLaunchKernelGGL(ada_lo_kernel<F16>, dim3(p.H), dim3(256), 0, st, p, ws);
+  const size_t lds = ((size_t)p.L * 2 + 15) & ~(size_t)15;
+  auto k_stats = dtype == 0 ? ada_stats_kernel<BF16> : ada_stats_kernel<F16>;
+  auto k_lo = dtype == 0 ? ada_lo_kernel<BF16> : ada_lo_kernel<F16>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
   }
+  hipLaunchKernelGGL(k_stats, dim3(p.H), dim3(256), lds, st, p, ws);
+  hipLaunchKernelGGL(k_lo, dim3(p.H), dim3(256), lds, st, p, ws);
   hipLaunchKernelGGL(ada_final_kernel, dim3(1), dim3(256), 0, st, p, ws, omf);
   return hipGetLastError();
 }

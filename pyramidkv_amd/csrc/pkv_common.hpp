@@ -70,19 +70,19 @@ template <typename T> __device__ __forceinline__ uint32_t order_key_pk(uint32_t 
   return __builtin_bit_cast(uint32_t, k);
 }
 
-// exp(x) for x <= ~0 (softmax arguments): Cody-Waite reduction + v_exp_f32 on |t| <= 0.5, ~1.5 ulp.
-// The model-dtype rounding that follows every use absorbs it exactly as it absorbs ATen's own
-// vectorised exp (tests bound the disagreement with the CPU oracle).  -inf, x < -104 and NaN give +0.
+// exp(x) for x <= ~0 (softmax arguments), ~1.4 ulp: range reduction in the log2 domain with a two-term
+// log2(e) (f = x*log2e - n is formed by two FMAs, exact to ~2^-48 before its single rounding), v_exp_f32 on
+// |f| <= 0.5, ldexp.  Branch-free; -inf, NaN and x < -104 give +0 (the result underflows in ldexp).
+// The model-dtype rounding that follows every use absorbs the last-ulp differences exactly as it absorbs
+// those of ATen's own vectorised exp (tests bound the disagreement with the CPU oracle).
 __device__ __forceinline__ float pkv_exp(float x) {
-  // branch-free: evaluate on a clamped argument, then select the underflow / NaN results
   const float xc = fmaxf(x, -104.0f);
-  const float L2E = 1.44269504088896340736f;
-  const float n = rintf(xc * L2E);
-  float r = fmaf(n, -0.693145751953125f, xc);            // ln2_hi: 12 trailing zero bits, n*ln2_hi exact
-  r = fmaf(n, -1.42860682030941723212e-6f, r);           // ln2_lo
-  const float p = __builtin_amdgcn_exp2f(r * L2E);       // v_exp_f32, argument in [-0.5, 0.5]
-  const float e = ldexpf(p, (int)n);
-  return (x > -104.0f) ? e : 0.0f;                       // NaN arguments give 0 (inputs are assumed finite)
+  const float L2E_HI = 1.44269502162933349609375f;       // fp32(log2 e)
+  const float L2E_LO = 1.92596299112661746e-8f;          // log2 e - L2E_HI
+  const float n = rintf(xc * L2E_HI);
+  float f = fmaf(xc, L2E_HI, -n);
+  f = fmaf(xc, L2E_LO, f);
+  return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 
 // correctly rounded x / c for a loop-invariant c (rc = RN(1/c)): one Newton-Markstein correction step.
@@ -90,6 +90,17 @@ __device__ __forceinline__ float div_const(float x, float c, float rc) {
   const float q = x * rc;
   const float r = fmaf(-q, c, x);
   return fmaf(r, rc, q);
+}
+
+// "attn / math.sqrt(head_dim)" (reference pyramidkv_utils.py:317) on a value already rounded to the model
+// dtype, result about to be rounded to the model dtype again.  head_dim is 128 in this build, and for
+// bf16 round(x / sqrt(128)) == round(x * fp32(1/sqrt(128))) for EVERY finite bf16 x (exhaustive check in
+// tests/test_abi_and_host.py), so both scale modes use the one-instruction multiply.  fp16 has 52 inputs
+// where the two differ: "div" mode keeps the correctly rounded division there.
+template <typename T> __device__ __forceinline__ float scale_logit(float x, int scale_mode, float c, float rc);
+template <> __device__ __forceinline__ float scale_logit<BF16>(float x, int, float, float rc) { return x * rc; }
+template <> __device__ __forceinline__ float scale_logit<F16>(float x, int scale_mode, float c, float rc) {
+  return scale_mode == 0 ? div_const(x, c, rc) : x * rc;
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

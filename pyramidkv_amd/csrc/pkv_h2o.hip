@@ -22,12 +22,12 @@ typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8_t;
 
 template <typename T> struct Mfma2;
 template <> struct Mfma2<BF16> {
-  static __device__ __forceinline__ f32x4 run(uint4 a, uint4 b, f32x4 c) {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
 };
 template <> struct Mfma2<F16> {
-  static __device__ __forceinline__ f32x4 run(uint4 a, uint4 b, f32x4 c) {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
@@ -35,19 +35,61 @@ template <> struct Mfma2<F16> {
 template <typename T>
 __device__ __forceinline__ float logit_chain(float acc, const H2OParams& p) {
   float x = Elem<T>::to_f32(Elem<T>::from_f32(acc));                       // matmul output dtype (:544)
-  x = (p.scale_mode == 0) ? div_const(x, p.sqrt_d, p.rcp_sqrt_d) : (x * p.rcp_sqrt_d);   // / math.sqrt(head_dim), exact
+  x = scale_logit<T>(x, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);             // / math.sqrt(head_dim)
   return Elem<T>::to_f32(Elem<T>::from_f32(x));
 }
 
-__device__ __forceinline__ void load_frags(uint4 (&f)[4], const uint16_t* base, int64_t row, int64_t stride, int lg) {
+// ------------------------------------------------------------------------------------------------
+// Tiling shared by both passes.  A workgroup (4 waves) keeps 256 "resident" rows in registers as MFMA
+// B operands (64 per wave = 4 column tiles x 4 k-steps x 16 B per lane) and streams the other matrix
+// in 64-row tiles through LDS, where all four waves read it (one L2 read per workgroup instead of one
+// per wave: without this the kernels are L2-bandwidth bound).  Staging is global -> VGPR -> ds_write,
+// double buffered, the next tile's global loads in flight while the current one is consumed.
+// LDS tile = [64 rows][16 chunks of 16 B]; chunk c of row r is stored at chunk c ^ (r & 15), so the
+// A-fragment read (lane (li, lg) reads row li, chunk kk*4+lg) is bank-conflict free.
+// ------------------------------------------------------------------------------------------------
+constexpr int HT = 64;                 // streamed rows per LDS tile
+constexpr int HR = 64;                 // resident rows per wave
+constexpr int HWG = 4 * HR;            // resident rows per workgroup
+
+struct Stager {                        // one thread's share of a 64 x 256 B tile: 4 x 16 B
+  u32x4 v[4];
+};
+
+__device__ __forceinline__ void stage_load(Stager& st, const uint16_t* base, int64_t stride, int row0, int nrows, int tid) {
+  const int c = tid & 15, r0 = tid >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = row0 + r0 + 16 * i;
+    r = r < nrows ? r : nrows - 1;                                            // clamp: masked by the consumer
+    st.v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)r * stride + c * 8);
+  }
+}
+__device__ __forceinline__ void stage_store(const Stager& st, u32x4* tile, int tid) {
+  const int c = tid & 15, r0 = tid >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + 16 * i;
+    tile[r * 16 + (c ^ (r & 15))] = st.v[i];
+  }
+}
+__device__ __forceinline__ void read_frags(u32x4 (&f)[4], const u32x4* tile, int sub, int li, int lg) {
+  const int r = sub * 16 + li;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) f[kk] = tile[r * 16 + ((kk * 4 + lg) ^ li)];
+}
+__device__ __forceinline__ void load_frags(u32x4 (&f)[4], const uint16_t* base, int64_t row, int64_t stride, int lg) {
   const uint16_t* r = base + row * stride + lg * 8;
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const uint4*>(r + kk * 32);
+  for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const u32x4*>(r + kk * 32);
 }
 
-// one workgroup = 128 query rows (4 waves x 32); loop over all S keys
+// Pass 1: per query row, max and sum of exp over all keys.  Resident = 256 query rows, streamed = K.
+// Per-lane online statistics (lane's column = one query, 4 keys per 16-key subtile); the running maximum
+// is only rescaled when some lane of the wave actually found a larger logit (wave-uniform branch).
 template <typename T>
 __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
+  __shared__ __attribute__((aligned(16))) u32x4 tiles[2][HT * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y;
@@ -55,51 +97,69 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
   const int S = p.S, L = S - p.w;
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b + (int64_t)h * p.qs_h;
   const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * HWG + wave * HR;
   const float fmin_v = Elem<T>::finfo_min();
+  const bool corner_wave = q0 + HR > L;          // this wave holds observation-window rows (wave-uniform)
 
-  uint4 qf[2][4];
-  int qi[2];
+  u32x4 qf[4][4];
+  int qi[4];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < 4; ++n) {
     qi[n] = q0 + n * 16 + li;
     load_frags(qf[n], qb, qi[n] < S ? qi[n] : S - 1, p.qs_s, lg);
   }
-  float m[2] = {-INFINITY, -INFINITY}, Z[2] = {0.f, 0.f};
+  float m[4], Z[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { m[n] = -INFINITY; Z[n] = 0.f; }
 
-  for (int s0 = 0; s0 < S; s0 += 16) {
-    uint4 kf[4];
-    const int sr = s0 + li;
-    load_frags(kf, kb, sr < S ? sr : S - 1, p.ks_s, lg);
+  Stager stg;
+  stage_load(stg, kb, p.ks_s, 0, S, tid);
+  stage_store(stg, tiles[0], tid);
+  __syncthreads();
+  const int ntiles = (S + HT - 1) / HT;
+  for (int t = 0; t < ntiles; ++t) {
+    const int s_tile = t * HT;
+    const u32x4* cur = tiles[t & 1];
+    if (t + 1 < ntiles) stage_load(stg, kb, p.ks_s, s_tile + HT, S, tid);     // in flight during the compute below
+    const bool edge = (s_tile + HT > S) || (corner_wave && s_tile + HT > L);  // wave-uniform: tail / masked corner
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int sub = 0; sub < 4; ++sub) {
+      u32x4 kf[4];
+      read_frags(kf, cur, sub, li, lg);
+      const int s0 = s_tile + sub * 16;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc = Mfma2<T>::run(kf[kk], qf[n][kk], acc);
-      float x[4];
-      float mx = -INFINITY;
+      for (int n = 0; n < 4; ++n) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int s = s0 + lg * 4 + r;
-        float v = logit_chain<T>(acc[r], p);
-        if (qi[n] >= L && s >= L && (s - L) > (qi[n] - L))                  // corner mask (:545-551)
-          v = Elem<T>::to_f32(Elem<T>::from_f32(v + fmin_v));
-        x[r] = (s < S) ? v : -INFINITY;
-        mx = fmaxf(mx, x[r]);
-      }
-      const float mn = fmaxf(m[n], mx);
-      if (mn != -INFINITY) {
-        float z = Z[n] * pkv_exp(m[n] - mn);
+        for (int kk = 0; kk < 4; ++kk) acc = Mfma2<T>::run(kf[kk], qf[n][kk], acc);
+        float x[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z += pkv_exp(x[r] - mn);
-        Z[n] = z;
-        m[n] = mn;
+        for (int r = 0; r < 4; ++r) x[r] = logit_chain<T>(acc[r], p);
+        if (edge) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int s = s0 + lg * 4 + r;
+            if (qi[n] >= L && s >= L && (s - L) > (qi[n] - L))                // corner mask (:545-551)
+              x[r] = Elem<T>::to_f32(Elem<T>::from_f32(x[r] + fmin_v));
+            if (s >= S) x[r] = -INFINITY;
+          }
+        }
+        const float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        if (__any(mx > m[n])) {                                               // rare once the maxima settle
+          const float mn = fmaxf(m[n], mx);
+          Z[n] = (m[n] == -INFINITY) ? 0.f : Z[n] * pkv_exp(m[n] - mn);
+          m[n] = mn;
+        }
+        const float mm = m[n];
+        Z[n] += (pkv_exp(x[0] - mm) + pkv_exp(x[1] - mm)) + (pkv_exp(x[2] - mm) + pkv_exp(x[3] - mm));
       }
     }
+    if (t + 1 < ntiles) stage_store(stg, tiles[(t + 1) & 1], tid);            // buffer last read in iteration t-1
+    __syncthreads();
   }
   float2* rs = p.rowstat + (int64_t)bh * S;
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < 4; ++n) {
     float mm = m[n], zz = Z[n];
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
@@ -113,9 +173,12 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
   }
 }
 
-// one workgroup = 128 key columns (4 waves x 32); loop over all S query rows
+// Pass 2: per key column, sum over all query rows of round(exp(x - m) / Z).  Resident = 256 key columns,
+// streamed = Q (+ the 64 row statistics of the tile).
 template <typename T>
 __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
+  __shared__ __attribute__((aligned(16))) u32x4 tiles[2][HT * 16];
+  __shared__ float2 stats[2][HT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y;
@@ -124,45 +187,70 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b + (int64_t)h * p.qs_h;
   const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const float2* rs = p.rowstat + (int64_t)bh * S;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int k0 = blockIdx.x * HWG + wave * HR;
 
-  uint4 kf[2][4];
-  int kj[2];
+  u32x4 kf[4][4];
+  int kj[4];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < 4; ++n) {
     kj[n] = k0 + n * 16 + li;
     load_frags(kf[n], kb, kj[n] < S ? kj[n] : S - 1, p.ks_s, lg);
   }
-  float col[2] = {0.f, 0.f};
+  float col[4] = {0.f, 0.f, 0.f, 0.f};
 
-  for (int i0 = 0; i0 < S; i0 += 16) {
-    uint4 qf[4];
-    const int ir = i0 + li;
-    load_frags(qf, qb, ir < S ? ir : S - 1, p.qs_s, lg);
-    float2 st[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + lg * 4 + r;
-      st[r] = rs[i < S ? i : S - 1];
+  Stager stg;
+  float2 sreg = make_float2(0.f, 0.f);
+  stage_load(stg, qb, p.qs_s, 0, S, tid);
+  if (tid < HT) sreg = rs[tid < S ? tid : S - 1];
+  stage_store(stg, tiles[0], tid);
+  if (tid < HT) stats[0][tid] = sreg;
+  __syncthreads();
+  const int ntiles = (S + HT - 1) / HT;
+  for (int t = 0; t < ntiles; ++t) {
+    const int i_tile = t * HT;
+    const u32x4* cur = tiles[t & 1];
+    const float2* cst = stats[t & 1];
+    if (t + 1 < ntiles) {
+      stage_load(stg, qb, p.qs_s, i_tile + HT, S, tid);
+      if (tid < HT) { const int i = i_tile + HT + tid; sreg = rs[i < S ? i : S - 1]; }
     }
+    const bool tail = i_tile + HT > S;                                        // wave-uniform
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int sub = 0; sub < 4; ++sub) {
+      u32x4 qf[4];
+      read_frags(qf, cur, sub, li, lg);
+      float2 st[4];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc = Mfma2<T>::run(qf[kk], kf[n][kk], acc);   // D[query][key]
+      for (int r = 0; r < 4; ++r) st[r] = cst[sub * 16 + lg * 4 + r];
+      const int i0 = i_tile + sub * 16;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = i0 + lg * 4 + r;
-        const float x = logit_chain<T>(acc[r], p);       // keys < L never touch the masked corner
-        const float pr = pkv_exp(x - st[r].x) * st[r].y;    // fp32 softmax (:553)
-        const float pq = Elem<T>::to_f32(Elem<T>::from_f32(pr));
-        if (i < S) col[n] += pq;                         // sum over all rows, fp32 (:554)
+      for (int n = 0; n < 4; ++n) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = Mfma2<T>::run(qf[kk], kf[n][kk], acc);   // D[query][key]
+        float pq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = logit_chain<T>(acc[r], p);           // keys < L never touch the masked corner
+          const float pr = pkv_exp(x - st[r].x) * st[r].y;     // fp32 softmax (:553)
+          pq[r] = Elem<T>::to_f32(Elem<T>::from_f32(pr));
+        }
+        if (tail) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (i0 + lg * 4 + r >= S) pq[r] = 0.f;
+        }
+        col[n] += (pq[0] + pq[1]) + (pq[2] + pq[3]);           // sum over all rows, fp32 (:554)
       }
     }
+    if (t + 1 < ntiles) {
+      stage_store(stg, tiles[(t + 1) & 1], tid);
+      if (tid < HT) stats[(t + 1) & 1][tid] = sreg;
+    }
+    __syncthreads();
   }
   uint16_t* out = reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride;
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < 4; ++n) {
     float c = col[n];
     c += __shfl_xor(c, 16, 64);
     c += __shfl_xor(c, 32, 64);
@@ -176,7 +264,7 @@ template __global__ void h2o_colsum_kernel<BF16>(H2OParams);
 template __global__ void h2o_colsum_kernel<F16>(H2OParams);
 
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
-  dim3 grid((p.S + 127) / 128, p.B * p.H);
+  dim3 grid((p.S + HWG - 1) / HWG, p.B * p.H);
   if (dtype == 0) hipLaunchKernelGGL(h2o_stats_kernel<BF16>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(h2o_stats_kernel<F16>, grid, dim3(256), 0, st, p);
   return hipGetLastError();
@@ -184,7 +272,7 @@ hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
 
 hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st) {
   const int L = p.S - p.w;
-  dim3 grid((L + 127) / 128, p.B * p.H);
+  dim3 grid((L + HWG - 1) / HWG, p.B * p.H);
   if (dtype == 0) hipLaunchKernelGGL(h2o_colsum_kernel<BF16>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(h2o_colsum_kernel<F16>, grid, dim3(256), 0, st, p);
   return hipGetLastError();

@@ -125,8 +125,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = Elem<T>::to_f32(Elem<T>::from_f32(acc[r]));                     // matmul output dtype (:317)
-        x = (p.scale_mode == 0) ? div_const(x, p.sqrt_d, p.rcp_sqrt_d)            // "/ math.sqrt(head_dim)" (:317), exact
-                                : (x * p.rcp_sqrt_d);
+        x = scale_logit<T>(x, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);               // "/ math.sqrt(head_dim)" (:317)
         uint16_t y = Elem<T>::from_f32(x);
         const int s = sg0 + r;
         if (s >= L && (s - L) > rr_c)                                              // strict upper corner (:318-324)

@@ -602,44 +602,106 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// sort_rows_kernel: full stable descending sort of one score row (L <= 32768) in LDS.
+// sort_rows_kernel: full stable descending sort of one score row (L <= 32768), one workgroup per row.
+// Two stable LSD radix passes over the 16-bit keys (low byte, then high byte): the input is in index
+// order, so the result is (value desc, index asc) - the reference's attn_score.sort(descending=True) with
+// the tie order pinned.  Ranking inside a wave uses match-any ballots (no atomics); composites
+// (key<<16 | index) ping-pong through the sorted_idx output buffer, which every thread re-reads into
+// registers before anything is overwritten.
 // ------------------------------------------------------------------------------------------------
+constexpr int SR_MAX_L = 32768;
+
+// match-any: the set of valid lanes of the wave that hold the same 8-bit digit
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+  uint64_t peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const uint64_t bb = __ballot(valid && bit);
+    peers &= bit ? bb : ~bb;
+  }
+  return peers;
+}
+
 template <typename T>
 __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* sel = reinterpret_cast<uint32_t*>(smem);
-  const int tid = threadIdx.x;
+  uint32_t* comp = reinterpret_cast<uint32_t*>(smem);                   // [n] composites, list order
+  uint32_t* table = comp + p.n;                                         // [16][256]
+  uint32_t* tot = table + TK_WAVES * 256;                               // [256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = blockIdx.x;
-  const int L = p.L, n = p.n;
+  const int L = p.L;
+  const int epw = (L + TK_THREADS - 1) / TK_THREADS;         // 64-element steps per wave
   const uint16_t* src = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)row * p.scores_stride;
-  for (int i = tid; i < n; i += TK_THREADS)
-    sel[i] = (i < L) ? ((order_key<T>(src[i]) << 16) | (0xffffu - (uint32_t)i)) : 0u;
-  __syncthreads();
-  for (int size = 2; size <= n; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (n >> 1); t += TK_THREADS) {
-        const int a = 2 * t - (t & (stride - 1));
-        const int b = a + stride;
-        const bool desc = (a & size) == 0;
-        const uint32_t va = sel[a], vb = sel[b];
-        if ((va < vb) == desc) { sel[a] = vb; sel[b] = va; }
+  uint32_t* buf = reinterpret_cast<uint32_t*>(p.sorted_idx + (int64_t)row * L);
+  uint16_t* ov = p.sorted_val ? reinterpret_cast<uint16_t*>(p.sorted_val) + (int64_t)row * L : nullptr;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  for (int i = tid; i < L; i += TK_THREADS) comp[i] = (order_key<T>(src[i]) << 16) | (uint32_t)i;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = tid; i < TK_WAVES * 256; i += TK_THREADS) table[i] = 0;
+    __syncthreads();
+    // sweep A: per-wave digit counts (wave w owns the contiguous list segment [w*epw*64, (w+1)*epw*64))
+    for (int e = 0; e < epw; ++e) {
+      const int i = wave * epw * 64 + e * 64 + lane;
+      const bool valid = i < L;
+      const uint32_t c = valid ? comp[i] : 0u;
+      const uint32_t d = 255u - ((c >> (16 + 8 * pass)) & 255u);        // ascending d == descending key
+      const uint64_t peers = match_digit(d, valid);
+      if (valid && (peers & lt) == 0ull) table[wave * 256 + d] += (uint32_t)__popcll(peers);   // group leader
+    }
+    __syncthreads();
+    if (tid < 256) {                                          // per digit: exclusive prefix over the 16 waves
+      uint32_t run = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < TK_WAVES; ++w2) {
+        const uint32_t c = table[w2 * 256 + tid];
+        table[w2 * 256 + tid] = run;
+        run += c;
       }
+      tot[tid] = run;
+    }
+    __syncthreads();
+    if (tid < 64) {                                           // exclusive prefix over the 256 digit totals
+      const uint4 h = reinterpret_cast<const uint4*>(tot)[tid];
+      const uint32_t own = h.x + h.y + h.z + h.w;
+      const uint32_t excl = wave_incl_scan_u32(own) - own;
+      reinterpret_cast<uint4*>(tot)[tid] = make_uint4(excl, excl + h.x, excl + h.x + h.y, excl + h.x + h.y + h.z);
+    }
+    __syncthreads();
+    for (int i = tid; i < TK_WAVES * 256; i += TK_THREADS) table[i] += tot[i & 255];   // absolute base of (wave, digit)
+    __syncthreads();
+    // sweep B: same ranking against the absolute bases: output positions come out directly (stable)
+    for (int e = 0; e < epw; ++e) {
+      const int i = wave * epw * 64 + e * 64 + lane;
+      const bool valid = i < L;
+      const uint32_t c = valid ? comp[i] : 0u;
+      const uint32_t d = 255u - ((c >> (16 + 8 * pass)) & 255u);
+      const uint64_t peers = match_digit(d, valid);
+      const uint32_t before = (uint32_t)__popcll(peers & lt);
+      uint32_t prev = 0;
+      if (valid) prev = table[wave * 256 + d];                // every peer reads the running base ...
+      if (valid && before == 0) table[wave * 256 + d] = prev + (uint32_t)__popcll(peers);   // ... the leader advances it
+      if (valid) {
+        const uint32_t pos = prev + before;
+        if (pass == 0) {
+          buf[pos] = c;                                       // composites ping-pong through the output buffer
+        } else {
+          const uint32_t idx = c & 0xffffu;
+          buf[pos] = idx;
+          if (ov) ov[pos] = src[idx];
+        }
+      }
+    }
+    if (pass == 0) {
+      __threadfence_block();
+      __syncthreads();
+      for (int i = tid; i < L; i += TK_THREADS) comp[i] = __builtin_nontemporal_load(buf + i);   // back in list order
       __syncthreads();
     }
   }
-  int32_t* oi = p.sorted_idx + (int64_t)row * L;
-  uint16_t* ov = p.sorted_val ? reinterpret_cast<uint16_t*>(p.sorted_val) + (int64_t)row * L : nullptr;
-  for (int i = tid; i < L; i += TK_THREADS) {
-    const int idx = (int)(0xffffu - (sel[i] & 0xffffu));
-    oi[i] = idx;
-    if (ov) ov[i] = src[idx];
-  }
 }
-
-template __global__ void topk_kernel<BF16>(TopkParams);
-template __global__ void topk_kernel<F16>(TopkParams);
-template __global__ void sort_rows_kernel<BF16>(SortParams);
-template __global__ void sort_rows_kernel<F16>(SortParams);
 
 hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st) {
   auto fn = dtype == 0 ? topk_kernel<BF16> : topk_kernel<F16>;
@@ -653,7 +715,7 @@ hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hip
 
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st) {
   auto fn = dtype == 0 ? sort_rows_kernel<BF16> : sort_rows_kernel<F16>;
-  const size_t lds = (size_t)p.n * 4;
+  const size_t lds = (size_t)p.n * 4 + (size_t)TK_WAVES * 256 * 4 + 256 * 4;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -143,3 +143,21 @@ def test_missing_extension_fails_loudly(tmp_path, monkeypatch):
     with pytest.raises(ImportError, match="no CPU/PyTorch fallback"):
         N._load()
     importlib.reload(N)
+
+
+def test_bf16_scale_by_reciprocal_equals_division_exhaustively():
+    """csrc/pkv_common.hpp scale_logit<BF16>: for head_dim 128, round_bf16(x / sqrt(128)) ==
+    round_bf16(x * fp32(1/sqrt(128))) for EVERY finite bf16 x, so the kernels may multiply in both scale
+    modes; fp16 does have exceptions, which is why it keeps the exact division in "div" mode."""
+    import math
+    import numpy as np
+    c32 = np.float32(math.sqrt(128.0))
+    rc = float(np.float32(1.0) / c32)
+    bits16 = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    for tdt, expect_equal in ((torch.bfloat16, True), (torch.float16, False)):
+        x = bits16.view(tdt).float()
+        fin = torch.isfinite(x)
+        a = (x / float(c32)).to(tdt).view(torch.int16)
+        b = (x * torch.tensor(rc, dtype=torch.float32)).to(tdt).view(torch.int16)
+        same = bool((a == b)[fin].all())
+        assert same == expect_equal
