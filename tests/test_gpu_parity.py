@@ -517,3 +517,36 @@ def test_golden_fixtures_through_hip_path(P):
     _report("golden_through_hip", stats)
     rate = np.mean([s["same_score_sequence_as_reference"] for s in stats.values()])
     assert rate >= 0.9, stats
+
+
+# ----------------------------------------------------------------------------------------- adapter on the device
+def test_replace_llama_end_to_end_on_gpu(P):
+    """replace_llama('pyramidkv') with the real HIP clusters on a tiny random bf16 Llama: HF generate runs,
+    every layer's cache has the pyramid length, the compacted cache of layer 0 equals the oracle's gather of
+    the indices the HIP path selected from that layer's K/Q."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from pyramidkv_amd import monkeypatch as mp
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=97, hidden_size=512, intermediate_size=512, num_hidden_layers=4, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=128, max_position_embeddings=8192)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(DEV).eval()
+    S, cap, w = 2048, 64, 8
+    ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(1)).to(DEV)
+    with torch.no_grad():
+        base = model(ids).logits
+    try:
+        mp.replace_llama("pyramidkv")
+        for layer in model.model.layers:
+            c = layer.self_attn.config
+            c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = w, cap, 7, "maxpool", None
+        with torch.no_grad():
+            out = model.generate(ids, max_new_tokens=4, do_sample=False, return_dict_in_generate=True)
+            full = model(ids, past_key_values=transformers.DynamicCache(config=cfg), use_cache=True)
+        assert out.sequences.shape == (1, S + 4)
+        lens = [out.past_key_values.layers[i].keys.shape[2] for i in range(4)]
+        assert lens == [O.pyramid_budget(cap, w, 4, i, S)[1] + w + 3 for i in range(4)]
+        assert torch.allclose(full.logits.float(), base.float(), atol=2e-2, rtol=2e-2)
+        assert isinstance(model.model.layers[0].self_attn.kv_cluster, P.PyramidKVCluster)
+    finally:
+        mp.restore()

@@ -1,0 +1,142 @@
+"""Plumbing of replace_llama / replace_mistral on transformers 5.x with a tiny random-init model on CPU.
+The clusters are stood in for by the oracle here (the product clusters need a GPU); what is tested is the
+adapter: cache lengths per layer, position handling after compaction, pass-through equivalence, prompt
+logits untouched by compression (the prompt attends to the full K/V, reference llama_model.py:174)."""
+import types
+
+import pytest
+import torch
+
+from oracle import pkv_oracle as O
+
+transformers = pytest.importorskip("transformers")
+
+
+class _OracleCluster:
+    def __init__(self, kind, cfg, layer_idx, layers):
+        self.kind, self.cfg, self.layer_idx, self.layers = kind, cfg, layer_idx, layers
+
+    def update_kv(self, k, q, v, mask, groups):
+        c = self.cfg
+        if self.kind == "pyramidkv":
+            return O.pyramidkv_update_kv(k, q, v, c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling,
+                                         self.layers, self.layer_idx)
+        if self.kind == "snapkv":
+            return O.snapkv_update_kv(k, q, v, c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling)
+        if self.kind == "h2o":
+            return O.h2o_update_kv(k, q, v, c.window_size, c.max_capacity_prompt)
+        return O.streamingllm_update_kv(k, q, v, c.window_size, c.max_capacity_prompt)
+
+
+def _oracle_module():
+    m = types.SimpleNamespace()
+    m.init_pyramidkv = lambda self, n: setattr(self, "kv_cluster", _OracleCluster("pyramidkv", self.config, self.layer_idx, n))
+    m.init_snapkv = lambda self: setattr(self, "kv_cluster", _OracleCluster("snapkv", self.config, self.layer_idx, 0))
+    m.init_H2O = lambda self: setattr(self, "kv_cluster", _OracleCluster("h2o", self.config, self.layer_idx, 0))
+    m.init_StreamingLLM = lambda self: setattr(self, "kv_cluster", _OracleCluster("streamingllm", self.config, self.layer_idx, 0))
+    return m
+
+
+def _tiny(family):
+    torch.manual_seed(0)
+    kw = dict(vocab_size=97, hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+              num_key_value_heads=1, head_dim=128, max_position_embeddings=4096)
+    if family == "llama":
+        from transformers import LlamaConfig, LlamaForCausalLM
+        cfg = LlamaConfig(**kw)
+        model = LlamaForCausalLM(cfg)
+    else:
+        from transformers import MistralConfig, MistralForCausalLM
+        cfg = MistralConfig(sliding_window=None, **kw)
+        model = MistralForCausalLM(cfg)
+    return model.eval()
+
+
+@pytest.fixture
+def patched():
+    from pyramidkv_amd import monkeypatch as mp
+    saved = mp._cluster_module
+    mp._cluster_module = _oracle_module()
+    yield mp
+    mp._cluster_module = saved
+    mp.restore()
+
+
+@pytest.mark.parametrize("family", ["llama", "mistral"])
+@pytest.mark.parametrize("method", ["pyramidkv", "snapkv", "streamingllm", "h2o"])
+def test_generate_with_compacted_cache(patched, family, method):
+    model = _tiny(family)
+    S, new = 200, 6
+    ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        base = model(ids).logits
+    (patched.replace_llama if family == "llama" else patched.replace_mistral)(method)
+    cap, w = 64, 8
+    for layer in model.model.layers:
+        c = layer.self_attn.config
+        c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = w, cap, 7, "maxpool", None
+    from transformers import DynamicCache
+    cache = DynamicCache(config=model.config)
+    with torch.no_grad():
+        out = model(ids, past_key_values=cache, use_cache=True)
+    # the prompt itself attends to the full K/V: prompt logits are those of the unpatched model
+    assert torch.allclose(out.logits, base, atol=1e-4, rtol=1e-4)
+    H = model.config.num_attention_heads
+    want = []
+    for li in range(model.config.num_hidden_layers):
+        if method == "pyramidkv":
+            br, k = O.pyramid_budget(cap, w, model.config.num_hidden_layers, li, S)
+            want.append(S if br == "passthrough" else k + w)
+        else:
+            want.append(cap)
+    got = [cache.layers[li].keys.shape for li in range(model.config.num_hidden_layers)]
+    assert [g[2] for g in got] == want and all(g[1] == H for g in got)      # all H heads cached, reference :158-168
+    # decode: positions continue from S, the cache grows by one per step in every layer
+    nxt = out.logits[:, -1:].argmax(-1)
+    with torch.no_grad():
+        for t in range(new):
+            o = model(nxt, past_key_values=cache, use_cache=True,
+                      position_ids=torch.tensor([[S + t]]), cache_position=torch.tensor([S + t]))
+            nxt = o.logits[:, -1:].argmax(-1)
+            assert torch.isfinite(o.logits).all()
+    assert [cache.layers[li].keys.shape[2] for li in range(model.config.num_hidden_layers)] == [x + new for x in want]
+
+
+def test_passthrough_equals_unpatched_generation(patched):
+    model = _tiny("llama")
+    ids = torch.randint(0, 97, (1, 40), generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = model.generate(ids, max_new_tokens=8, do_sample=False)
+    patched.replace_llama("snapkv")
+    for layer in model.model.layers:
+        c = layer.self_attn.config
+        c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = 8, 64, 7, "maxpool", None   # 40 < 64: no eviction
+    with torch.no_grad():
+        got = model.generate(ids, max_new_tokens=8, do_sample=False)
+    assert torch.equal(ref, got)
+
+
+def test_unknown_method_raises(patched):
+    with pytest.raises(ValueError):
+        patched.replace_llama("adakv")
+
+
+@pytest.mark.parametrize("method", ["pyramidkv", "snapkv"])
+def test_hf_generate_runs_on_compacted_cache(patched, method):
+    """End-to-end ``model.generate`` (the reference runners' call, run_longbench.py:266-275) with eviction on."""
+    model = _tiny("llama")
+    S = 150
+    ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(3))
+    patched.replace_llama(method)
+    for layer in model.model.layers:
+        c = layer.self_attn.config
+        c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = 8, 48, 7, "maxpool", None
+    with torch.no_grad():
+        out = model.generate(ids, max_new_tokens=5, do_sample=False, return_dict_in_generate=True)
+    assert out.sequences.shape == (1, S + 5)
+    lens = [out.past_key_values.layers[i].keys.shape[2] for i in range(model.config.num_hidden_layers)]
+    # the last generated token is not fed back, so the cache holds the compacted prompt + 4 decoded tokens
+    if method == "snapkv":
+        assert lens == [48 + 4] * model.config.num_hidden_layers
+    else:
+        assert lens == [O.pyramid_budget(48, 8, model.config.num_hidden_layers, i, S)[1] + 8 + 4 for i in range(model.config.num_hidden_layers)]
