@@ -63,6 +63,12 @@ for dt in ("bf16", "fp16"):
     for pool, ks in (("maxpool", 7), ("avgpool", 5)):
         case(policy="snapkv", dtype=dt, kind="gauss", B=1, H=4, S=512, w=8, cap=64, ks=ks, pool=pool, seed=11)
         case(policy="snapkv", dtype=dt, kind="lattice", B=2, H=2, S=384, w=32, cap=96, ks=ks, pool=pool, seed=12)
+# tie-free cases: 64 planted heavy hitters with well separated scores and no pooling plateau (kernel 1), so even the
+# reference's CPU topk order is fully determined -> the HIP path must be BIT-IDENTICAL to the real reference here
+for dt in ("bf16", "fp16"):
+    case(policy="snapkv", dtype=dt, kind="planted", B=1, H=2, S=2048, w=8, cap=40, ks=1, pool="avgpool", seed=91, tie_free=True)
+    case(policy="pyramidkv", dtype=dt, kind="planted", B=1, H=2, S=2048, w=8, cap=24, ks=1, pool="maxpool", seed=92,
+         layers=32, layer=5, tie_free=True)
 case(policy="snapkv", dtype="fp32", kind="gauss", B=1, H=2, S=300, w=8, cap=40, ks=7, pool="maxpool", seed=13)
 case(policy="snapkv", dtype="bf16", kind="gauss", B=1, H=2, S=48, w=8, cap=64, ks=7, pool="maxpool", seed=14)  # passthrough
 for layer in (0, 15, 31):

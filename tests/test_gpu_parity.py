@@ -479,6 +479,10 @@ def test_golden_fixtures_through_hip_path(P):
             equiv = O.equivalent_selection(idx, ref_idx, s)
             exact = bool(np.array_equal(bits(kc), z["kc"]))
             stats[c["name"]] = dict(same_score_sequence_as_reference=equiv, bit_identical_to_reference=exact)
+            if c.get("tie_free"):
+                # no ties anywhere near the selection: the reference's own order is fully determined, so the HIP
+                # path must reproduce the REAL reference's output bit for bit (indices, K and V)
+                assert exact and np.array_equal(bits(vc), z["vc"]) and np.array_equal(idx.numpy().astype(np.int32), z["idx"]), c["name"]
         elif pol == "streamingllm":
             kc, vc = P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
             assert np.array_equal(bits(kc), z["kc"]) and np.array_equal(bits(vc), z["vc"])
@@ -550,3 +554,94 @@ def test_replace_llama_end_to_end_on_gpu(P):
         assert isinstance(model.model.layers[0].self_attn.kv_cluster, P.PyramidKVCluster)
     finally:
         mp.restore()
+
+
+# ----------------------------------------------------------------------------------------- full-size checks
+@pytest.mark.parametrize("B,cap", [(2, 128), (1, 2048), (2, 4096)])
+def test_full_size_selection_properties(P, B, cap):
+    """BASELINE-size call ([B,32,32768,128] bf16) checked through size-independent properties, computed
+    with plain torch ops on the device: valid index set, canonical order under the kernel's own scores,
+    top-k dominance (no rejected score beats a selected one), bit-exact gather incl. the window tail."""
+    H, S, w = 32, 32768, 8
+    g = torch.Generator(device=DEV).manual_seed(7)
+    q, k, v = (torch.randn(B, H, S, 128, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
+    kk = cap - w
+    kc, vc, idx = P.ops.compress(q, k, v, w, kk, "maxpool", 7, return_indices=True)
+    s = P.ops.score_window(q, k, w, "maxpool", 7)
+    idx64 = idx.long()
+    assert int(idx64.min()) >= 0 and int(idx64.max()) < S - w
+    assert bool((torch.sort(idx64, -1).values.diff(dim=-1) > 0).all())                 # distinct
+    sel = torch.gather(s, -1, idx64).float()
+    assert bool((sel.diff(dim=-1) <= 0).all())                                            # value descending
+    same = sel.diff(dim=-1) == 0
+    assert bool((idx64.diff(dim=-1)[same] > 0).all())                                     # ties: index ascending
+    rest = s.float().scatter(-1, idx64, float("-inf"))
+    assert bool((rest.max(-1).values <= sel[..., -1]).all())                              # dominance
+    # ties with the k-th value must have been resolved towards the lowest indices
+    kth = sel[..., -1:]
+    tie_rest = (rest == kth)
+    first_rejected_tie = torch.where(tie_rest.any(-1), tie_rest.float().argmax(-1), torch.full_like(idx64[..., 0], S))
+    last_selected_tie = torch.where(sel == kth, idx64, torch.full_like(idx64, -1)).max(-1).values
+    assert bool((last_selected_tie < first_rejected_tie).all())
+    gi = idx64.unsqueeze(-1).expand(-1, -1, -1, 128)
+    assert torch.equal(kc[:, :, :kk], k[:, :, :-w].gather(2, gi)) and torch.equal(vc[:, :, :kk], v[:, :, :-w].gather(2, gi))
+    assert torch.equal(kc[:, :, kk:], k[:, :, -w:]) and torch.equal(vc[:, :, kk:], v[:, :, -w:])
+
+
+@pytest.mark.parametrize("dt,w,pool,ks", [("bf16", 32, "avgpool", 5), ("fp16", 8, "maxpool", 7), ("fp16", 32, "avgpool", 5)])
+def test_window_scores_32k_variants(P, dt, w, pool, ks):
+    q, k, _ = make_qkv(1, 4, 32768, 128, dt, "gauss", 4321)
+    want = O.pool_scores(O.window_scores(q, k, w), pool, ks)
+    got = P.ops.score_window(q.to(DEV), k.to(DEV), w, pool, ks).cpu()
+    frac, mx = score_diff(got, want)
+    _report(f"window_scores/{dt}/gauss/S32768w{w}{pool}", dict(mismatch_frac=frac, max_ulp=mx))
+    assert mx <= 1 and frac <= SCORE_MISMATCH_FRAC, (frac, mx)
+
+
+def test_h2o_scores_8k_blocked_oracle(P):
+    q, k, _ = make_qkv(1, 2, 8192, 128, "bf16", "gauss", 88)
+    want = O.h2o_scores_blocked(q, k, 8, block=256)
+    got = P.ops.score_h2o(q.to(DEV), k.to(DEV), 8).cpu()
+    frac, mx = score_diff(got, want)
+    _report("h2o_scores/bf16/S8192", dict(mismatch_frac=frac, max_ulp=mx))
+    assert mx <= 1 and frac <= 0.05, (frac, mx)
+
+
+def test_adakv_32k_vs_oracle(P):
+    H, S, w, cap = 8, 32768, 8, 128
+    q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 63)
+    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2,
+                        normalize=True, layer_idx=0, num_hidden_layers=32)
+    kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
+    kr, vr, meta = O.adakv_update_kv(k, q, v, w, cap, 7, "maxpool", 0.2, True)
+    same_lens = cl.head_lens.cpu().tolist() == meta.head_lens.tolist()
+    same_kv = same_lens and bool(torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr))
+    _report("adakv_32k", dict(head_lens_identical=same_lens, kv_identical=same_kv, head_lens=cl.head_lens.cpu().tolist()))
+    assert int(cl.head_lens.sum()) == kf.shape[0] == cl.klen_sum
+    assert abs(int(cl.head_lens.sum()) - H * cap) <= H              # rounding of the per-head budgets (:719)
+    assert same_lens
+
+
+def test_config_knobs_gqa_dedup_and_scale_mode(P):
+    """config.gqa_dedup reads one head per GQA group of a repeat_kv'ed K/V and must give identical output;
+    scale_mode 'rcp' == 'div' bit for bit for bf16 (proved exhaustively on the host side)."""
+    B, Hkv, g, S, w, cap = 1, 2, 4, 4096, 8, 128
+    q, k8, v8 = make_qkv(B, Hkv * g, S, 128, "bf16", "gauss", 71)
+    k = k8[:, ::g][:, :, None].expand(B, Hkv, g, S, 128).reshape(B, Hkv * g, S, 128).contiguous()   # repeat_kv output
+    v = v8[:, ::g][:, :, None].expand(B, Hkv, g, S, 128).reshape(B, Hkv * g, S, 128).contiguous()
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+    ref = cl.update_kv(kd, qd, vd, None, g)
+    try:
+        P.config.gqa_dedup = True
+        ded = cl.update_kv(kd, qd, vd, None, g)
+        P.config.gqa_dedup = False
+        P.config.scale_mode = "rcp"
+        rcp = cl.update_kv(kd, qd, vd, None, g)
+    finally:
+        P.config.gqa_dedup = False
+        P.config.scale_mode = "div"
+    for a, b in zip(ref, ded):
+        assert torch.equal(a, b)
+    for a, b in zip(ref, rcp):
+        assert torch.equal(a, b)

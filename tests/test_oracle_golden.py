@@ -130,6 +130,15 @@ def test_flat_canonical_equivalent_to_reference(c):
         off += n
 
 
+def test_tie_free_fixtures_canonical_is_bit_identical_to_reference():
+    """On the tie-free fixtures the oracle's canonical tie rule and the reference's CPU topk coincide exactly."""
+    for c in [c for c in CASES if c.get("tie_free")]:
+        z, q, k, v = _load(c)
+        kc, vc, idx = _run(c, q, k, v, "canonical")
+        assert np.array_equal(bits(kc), z["kc"]) and np.array_equal(bits(vc), z["vc"])
+        assert np.array_equal(idx.numpy().astype(np.int32), z["idx"])
+
+
 def test_pyramid_budget_table():
     # SURVEY section 8a1: cap=128,w=8,32 layers,S>=8192 -> 234,227,...,17 (sum 4016)
     ks = [O.pyramid_budget(128, 8, 32, l, 8192)[1] for l in range(32)]

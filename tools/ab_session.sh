@@ -7,6 +7,4 @@ mkdir -p $O
 cd $R
 timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.txt 2>&1
 echo "pytest exit $?" >> $O/pytest.txt
-timeout 900 python tools/policy_bench.py > $O/policy_bench.json 2> $O/policy_bench.err
-timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
-tail -4 $O/pytest.txt
+tail -30 $O/pytest.txt
