@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--policy", default="pyramidkv", choices=["pyramidkv", "snapkv"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=4)
     return ap.parse_args()
 
@@ -179,6 +180,31 @@ def main():
         "roofline": kernels.get("logits"),
         "roofline_kernels": kernels,
     }
+
+    # extra (not `value`): the same workload when K/V really are repeat_kv output of 8 KV heads (Llama-3-8B /
+    # Mistral-7B) and the caller opts into reading one head per GQA group (config.gqa_dedup)
+    if world == 1 and not a.no_extras and Hl % 4 == 0:
+        gsets = []
+        for (q, k, v) in sets:
+            k4 = k[:, ::4][:, :, None].expand(B, Hl // 4, 4, S, D).reshape(B, Hl, S, D).contiguous()
+            v4 = v[:, ::4][:, :, None].expand(B, Hl // 4, 4, S, D).reshape(B, Hl, S, D).contiguous()
+            gsets.append((q, k4, v4))
+
+        def gstep():
+            for layer in range(NUM_LAYERS):
+                q, k, v = gsets[layer % NSETS]
+                P.ops.compress(q, k[:, ::4], v[:, ::4], w, ks[layer], "maxpool", 7, kv_group=4)
+        gstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            gstep()
+        torch.cuda.synchronize()
+        ge = time.perf_counter() - t0
+        out["extras"] = {"gqa_dedup_tokens_per_s": round(B * S * a.steps / ge, 1),
+                         "gqa_dedup_us_per_layer": round(ge / a.steps / NUM_LAYERS * 1e6, 2),
+                         "note": "K/V = repeat_kv of 8 KV heads, kernels read 1 head per group (opt-in config.gqa_dedup); not the headline value"}
+        del gsets
 
     if rank == 0 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sets[0], ks, w, cap, a)
