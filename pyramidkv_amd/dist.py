@@ -48,3 +48,35 @@ class HeadShardedCluster:
     def update_kv(self, key_states, query_states, value_states):
         kc, vc, idx = self.select_fn(query_states, key_states, value_states)
         return kc, vc, allgather_indices(idx, self.group)
+
+
+class HeadShardedAdaKV:
+    """Ada-SnapKV with heads sharded over ranks.  The per-layer budget couples ALL heads
+    (flattened top-(H*base), reference pyramidkv_utils.py:712-717), so there is one exchange step: an
+    all-gather of every rank's per-head SORTED score rows ([H/N, L] 16-bit values, 64 KB per head at S=32k);
+    every rank then evaluates the budgets of all H heads and keeps the capacities of its own.  The flat K/V
+    output and its var-len metadata stay local to the rank (its heads only).
+
+    ``score_sort_fn(q, k) -> (sorted_idx [Hl, L] int32, sorted_val [Hl, L])`` and
+    ``budget_fn(sorted_val_all [H, L]) -> capacities int32 [H]`` and
+    ``gather_fn(k, v, sorted_idx, cap_local) -> (K_flat, V_flat, head_lens, cu_klen)`` are the local stages
+    (HIP ops on a GPU; tests pass oracle stand-ins on CPU)."""
+
+    def __init__(self, score_sort_fn, budget_fn, gather_fn, group: Optional[dist.ProcessGroup] = None):
+        self.score_sort_fn, self.budget_fn, self.gather_fn, self.group = score_sort_fn, budget_fn, gather_fn, group
+
+    def update_kv(self, key_states, query_states, value_states):
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        sorted_idx, sorted_val = self.score_sort_fn(query_states, key_states)
+        Hl, L = sorted_val.shape
+        if world > 1:
+            allv = torch.empty(world * Hl, L, dtype=sorted_val.dtype, device=sorted_val.device)
+            # 16-bit payloads travel as raw bytes so that every backend (gloo included) accepts them
+            dist.all_gather_into_tensor(allv.view(torch.uint8), sorted_val.contiguous().view(torch.uint8), group=self.group)
+        else:
+            allv = sorted_val
+        cap_all = self.budget_fn(allv)                                   # [H] on every rank, identical
+        cap_local = cap_all[rank * Hl:(rank + 1) * Hl].contiguous()
+        kf, vf, head_lens, cu_klen = self.gather_fn(key_states, value_states, sorted_idx, cap_local)
+        return kf, vf, head_lens, cu_klen, cap_all

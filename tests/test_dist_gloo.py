@@ -59,3 +59,49 @@ def test_shard_heads_partition():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(N - 1))
     with pytest.raises(ValueError):
         pdist.shard_heads(30, 0, 4)
+
+
+def _ada_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyramidkv_amd import dist as pdist
+    H, S, w, cap, floor = 8, 512, 8, 64, 0.2
+    q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 11)
+    h0, h1 = pdist.shard_heads(H, rank, world)
+    base = cap - w
+
+    def score_sort(ql, kl):
+        s = O.pool_scores(O.window_scores(ql, kl, w, "mean"), "maxpool", 7)
+        srt = torch.sort(s[0], dim=-1, descending=True, stable=True)
+        return srt.indices.int(), srt.values
+
+    def budget(allv):
+        # oracle budget on already-sorted rows (sorting again is the identity)
+        return O.adakv_head_capacity(allv[None], base, floor, True, "canonical")[1][0]
+
+    def gather(kl, vl, sidx, capl):
+        per_head = [sidx[h, :int(capl[h])].long() for h in range(sidx.shape[0])]
+        kf, vf, lens = O._flat_gather(kl, vl, per_head, w)
+        hl = torch.tensor(lens, dtype=torch.int32)
+        cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(hl, 0, dtype=torch.int32)])
+        return kf, vf, hl, cu
+
+    cl = pdist.HeadShardedAdaKV(score_sort, budget, gather)
+    kf, vf, hl, cu, cap_all = cl.update_kv(k[:, h0:h1], q[:, h0:h1], v[:, h0:h1])
+    kr, vr, meta = O.adakv_update_kv(k, q, v, w, cap, 7, "maxpool", floor, True)
+    lens = meta.head_lens.tolist()
+    off0, off1 = sum(lens[:h0]), sum(lens[:h1])
+    ok = hl.tolist() == lens[h0:h1] and torch.equal(kf, kr[off0:off1]) and torch.equal(vf, vr[off0:off1])
+    ok = ok and [int(c) + w for c in cap_all] == lens
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_head_sharded_adakv_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ada_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)

@@ -5,8 +5,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
-echo "smoke exit $?" >> $O/smoke.txt
-timeout 900 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
-echo "bench exit $?" >> $O/bench.err
-tail -3 $O/smoke.txt; cat $O/bench.json | cut -c1-3000; tail -2 $O/bench.err
+timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.txt 2>&1
+echo "pytest exit $?" >> $O/pytest.txt
+python tools/wg_trace.py > $O/wg_trace.json 2> $O/wg_trace.err
+timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench.json 2> $O/bench.err
+timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --seq 8192 > $O/bench8k.json 2> $O/bench8k.err
+tail -3 $O/pytest.txt
