@@ -27,6 +27,21 @@ template <> struct Elem<BF16> {
   static __device__ __forceinline__ bool is_nan(uint16_t h) { return (h & 0x7fffu) > 0x7f80u; }
 };
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> two model-dtype values packed in one dword (lo = a, hi = b): one v_cvt_pk_* instruction
+template <typename T> __device__ __forceinline__ uint32_t round_pack2(float a, float b);
+template <> __device__ __forceinline__ uint32_t round_pack2<BF16>(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+template <> __device__ __forceinline__ uint32_t round_pack2<F16>(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+
 template <> struct Elem<F16> {
   static __device__ __forceinline__ float to_f32(uint16_t h) {
     _Float16 x = __builtin_bit_cast(_Float16, h);

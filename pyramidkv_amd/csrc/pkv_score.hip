@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b;
   const float fmin_v = Elem<T>::finfo_min();
   const int ntile_c = (C + 15) >> 4;
+  const bool corner_tile = (t_idx + 1) * TILE > L;      // workgroup-uniform: this tile touches keys >= S - w
 
   for (int n = 0; n < ntile_c; ++n) {
     // B fragments: column c = n*16 + li -> Q[b, h0 + c/w, S - w + c%w, kk*32 + lg*8 ..]
@@ -118,26 +119,32 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
         if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e30f) p.partial[0] = make_float2(0.f, 0.f);
         continue;
       }
-      // epilogue: three roundings to the model dtype, as the reference materialises them
+      // epilogue: three roundings to the model dtype, as the reference materialises them; values are
+      // handled as packed pairs (one v_cvt_pk per two roundings), the corner mask only in the tiles
+      // that reach the observation window (wave-uniform branch)
       const int key0 = wave * KPW + t * 16 + lg * 4;       // key within the tile of acc[0]
       const int sg0 = t_idx * TILE + key0;                 // global key index
-      uint16_t o[4];
+      uint32_t p01 = round_pack2<T>(acc[0], acc[1]);                               // matmul output dtype (:317)
+      uint32_t p23 = round_pack2<T>(acc[2], acc[3]);
+      float x0 = Elem<T>::to_f32((uint16_t)(p01 & 0xffffu)), x1 = Elem<T>::to_f32((uint16_t)(p01 >> 16));
+      float x2 = Elem<T>::to_f32((uint16_t)(p23 & 0xffffu)), x3 = Elem<T>::to_f32((uint16_t)(p23 >> 16));
+      x0 = scale_logit<T>(x0, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);              // "/ math.sqrt(head_dim)" (:317)
+      x1 = scale_logit<T>(x1, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);
+      x2 = scale_logit<T>(x2, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);
+      x3 = scale_logit<T>(x3, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);
+      p01 = round_pack2<T>(x0, x1);
+      p23 = round_pack2<T>(x2, x3);
+      if (corner_tile) {                                                           // strict upper corner (:318-324)
+        uint16_t o[4] = {(uint16_t)(p01 & 0xffffu), (uint16_t)(p01 >> 16), (uint16_t)(p23 & 0xffffu), (uint16_t)(p23 >> 16)};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = Elem<T>::to_f32(Elem<T>::from_f32(acc[r]));                     // matmul output dtype (:317)
-        x = scale_logit<T>(x, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);               // "/ math.sqrt(head_dim)" (:317)
-        uint16_t y = Elem<T>::from_f32(x);
-        const int s = sg0 + r;
-        if (s >= L && (s - L) > rr_c)                                              // strict upper corner (:318-324)
-          y = Elem<T>::from_f32(Elem<T>::to_f32(y) + fmin_v);
-        o[r] = y;
+        for (int r = 0; r < 4; ++r) {
+          const int s = sg0 + r;
+          if (s >= L && (s - L) > rr_c) o[r] = Elem<T>::from_f32(Elem<T>::to_f32(o[r]) + fmin_v);
+        }
+        p01 = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        p23 = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
       }
-      if (c < C) {
-        uint2 pk;
-        pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-        pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-        *reinterpret_cast<uint2*>(tile + c * LROW + key0) = pk;
-      }
+      if (c < C) *reinterpret_cast<uint2*>(tile + c * LROW + key0) = make_uint2(p01, p23);
     }
   }
   if (p.ablate >= 1) return;   // measurement aid: no statistics / logits store
