@@ -74,12 +74,19 @@ def main():
     import pyramidkv_amd as P
     from pyramidkv_amd import _native as N, dist as pdist
 
+    # PKV_BENCH_BACKEND=gloo (+ all ranks on one GPU) exists only to exercise the N>1 code path on a 1-GPU box
+    backend = os.environ.get("PKV_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     e = 2
@@ -206,7 +213,7 @@ def main():
                          "note": "K/V = repeat_kv of 8 KV heads, kernels read 1 head per group (opt-in config.gqa_dedup); not the headline value"}
         del gsets
 
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sets[0], ks, w, cap, a)
     if rank == 0:
         print(json.dumps(out))

@@ -5,11 +5,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.txt 2>&1
-echo "pytest exit $?" >> $O/pytest.txt
-python tools/wg_trace.py > $O/wg_trace.json 2> $O/wg_trace.err
-timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench.json 2> $O/bench.err
-timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --seq 8192 > $O/bench8k.json 2> $O/bench8k.err
-PKV_FUSE_GATHER_ROWS=0 timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_nofuse.json 2> $O/bench_nofuse.err
-PKV_FUSE_GATHER_ROWS=0 timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --seq 8192 > $O/bench8k_nofuse.json 2> $O/bench8k_nofuse.err
-tail -3 $O/pytest.txt
+PKV_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 > $O/bench_n2_gloo.json 2> $O/bench_n2_gloo.err
+echo "exit $?" >> $O/bench_n2_gloo.err
+cat $O/bench_n2_gloo.json | cut -c1-900; tail -5 $O/bench_n2_gloo.err
