@@ -9,6 +9,12 @@
 //   h2o_stats_kernel   per query row: max and sum-of-exp over all keys (online softmax statistics)
 //   h2o_colsum_kernel  per key column: sum over all query rows of round(exp(x-m)/Z)
 // Both recompute the logits with mfma_f32_16x16x32 and apply the reference's three roundings.
+// exp: every probability is ONE v_exp_f32 of fma(x, log2e, c_row) with c_row = -(m*log2e + log2 Z) (the
+// 1/Z factor folded into the exponent), relative error ~|x*log2e| * 2^-24 (about 1e-6).  That is ~20x the
+// error of the window path's exp, and deliberately so: a score here is a sum over S >= 1000s of rounded
+// probabilities, so the rare rounding flips (1e-6 / 2^-9 per element) average out far below the model-dtype
+// resolution of the sum (measured against the oracle in tests/test_gpu_parity.py::test_h2o_*), while the
+// kernels are VALU-bound and the accurate exp costs 8 of ~18 vector instructions per S x S element.
 // Roofline: compute.  2*2*S^2*D*H flops per call on the matrix cores, plus ~60 VALU ops per S x S
 // element for the rounding chain / exp / division, which is what actually bounds it.
 #include "pkv_common.hpp"
@@ -108,9 +114,10 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
     qi[n] = q0 + n * 16 + li;
     load_frags(qf[n], qb, qi[n] < S ? qi[n] : S - 1, p.qs_s, lg);
   }
-  float m[4], Z[4];
+  const float L2E = 1.44269504088896340736f;
+  float m[4], mL[4], Z[4];          // running max, -max*log2e, running sum of exp
 #pragma unroll
-  for (int n = 0; n < 4; ++n) { m[n] = -INFINITY; Z[n] = 0.f; }
+  for (int n = 0; n < 4; ++n) { m[n] = -INFINITY; mL[n] = 0.f; Z[n] = 0.f; }
 
   Stager stg;
   stage_load(stg, kb, p.ks_s, 0, S, tid);
@@ -147,11 +154,13 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
         const float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
         if (__any(mx > m[n])) {                                               // rare once the maxima settle
           const float mn = fmaxf(m[n], mx);
-          Z[n] = (m[n] == -INFINITY) ? 0.f : Z[n] * pkv_exp(m[n] - mn);
+          Z[n] = (m[n] == -INFINITY) ? 0.f : Z[n] * __builtin_amdgcn_exp2f((m[n] - mn) * L2E);
           m[n] = mn;
+          mL[n] = (mn == -INFINITY) ? 0.f : -mn * L2E;
         }
-        const float mm = m[n];
-        Z[n] += (pkv_exp(x[0] - mm) + pkv_exp(x[1] - mm)) + (pkv_exp(x[2] - mm) + pkv_exp(x[3] - mm));
+        const float c = mL[n];
+        Z[n] += (__builtin_amdgcn_exp2f(fmaf(x[0], L2E, c)) + __builtin_amdgcn_exp2f(fmaf(x[1], L2E, c))) +
+                (__builtin_amdgcn_exp2f(fmaf(x[2], L2E, c)) + __builtin_amdgcn_exp2f(fmaf(x[3], L2E, c)));
       }
     }
     if (t + 1 < ntiles) stage_store(stg, tiles[(t + 1) & 1], tid);            // buffer last read in iteration t-1
@@ -165,11 +174,12 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
     for (int o = 16; o <= 32; o <<= 1) {
       const float mo = __shfl_xor(mm, o, 64), zo = __shfl_xor(zz, o, 64);
       const float mn = fmaxf(mm, mo);
-      const float za = (mm == -INFINITY) ? 0.f : zz * pkv_exp(mm - mn);
-      const float zb = (mo == -INFINITY) ? 0.f : zo * pkv_exp(mo - mn);
+      const float za = (mm == -INFINITY) ? 0.f : zz * __builtin_amdgcn_exp2f((mm - mn) * L2E);
+      const float zb = (mo == -INFINITY) ? 0.f : zo * __builtin_amdgcn_exp2f((mo - mn) * L2E);
       mm = mn; zz = za + zb;
     }
-    if (lg == 0 && qi[n] < S) rs[qi[n]] = make_float2(mm, 1.0f / zz);   // (row max, 1 / row sum): ATen CPU softmax multiplies
+    // c_row = -(m*log2e + log2 Z): pass 2 evaluates exp(x - m) / Z as exp2(x*log2e + c_row)
+    if (lg == 0 && qi[n] < S) rs[qi[n]] = make_float2(-(mm * L2E + __builtin_amdgcn_logf(zz)), 0.f);
   }
 }
 
@@ -197,6 +207,7 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
     load_frags(kf[n], kb, kj[n] < S ? kj[n] : S - 1, p.ks_s, lg);
   }
   float col[4] = {0.f, 0.f, 0.f, 0.f};
+  const float L2E2 = 1.44269504088896340736f;
 
   Stager stg;
   float2 sreg = make_float2(0.f, 0.f);
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float x = logit_chain<T>(acc[r], p);           // keys < L never touch the masked corner
-          const float pr = pkv_exp(x - st[r].x) * st[r].y;     // fp32 softmax (:553)
+          const float pr = __builtin_amdgcn_exp2f(fmaf(x, L2E2, st[r].x));   // fp32 softmax (:553): exp(x - m) / Z
           pq[r] = Elem<T>::to_f32(Elem<T>::from_f32(pr));
         }
         if (tail) {

@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-PKV_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 > $O/bench_n2_gloo.json 2> $O/bench_n2_gloo.err
-echo "exit $?" >> $O/bench_n2_gloo.err
-cat $O/bench_n2_gloo.json | cut -c1-900; tail -5 $O/bench_n2_gloo.err
+timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.txt 2>&1
+echo "pytest exit $?" >> $O/pytest.txt
+timeout 900 python tools/policy_bench.py > $O/policy_bench.json 2> $O/policy_bench.err
+tail -3 $O/pytest.txt
