@@ -370,7 +370,15 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
   dim3 grid(p.nT, p.B * (p.H / p.G));
   const int tile = p.tile;
   const size_t lds = (size_t)C * (tile + 8) * sizeof(uint16_t);
-#define PKV_LAUNCH(TT, KPW, NT) hipLaunchKernelGGL((logits_kernel<TT, KPW, NT>), grid, dim3(256), lds, st, p)
+#define PKV_LAUNCH(TT, KPW, NT)                                                                                         \
+  do {                                                                                                                 \
+    if (lds > 64 * 1024) {  /* wide GQA groups x wide windows: opt in to more than 64 KB of dynamic LDS */           \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(logits_kernel<TT, KPW, NT>),                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+      if (e_ != hipSuccess) return e_;                                                                                \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((logits_kernel<TT, KPW, NT>), grid, dim3(256), lds, st, p);                                    \
+  } while (0)
   if (dtype == 0) {
     if (tile == 128) { if (p.nt) PKV_LAUNCH(BF16, 32, true); else PKV_LAUNCH(BF16, 32, false); }
     else             { if (p.nt) PKV_LAUNCH(BF16, 64, true); else PKV_LAUNCH(BF16, 64, false); }

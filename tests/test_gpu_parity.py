@@ -240,6 +240,18 @@ def test_window_scores_scale_modes_and_gqa(P, mode):
     assert mx <= 1 and frac <= SCORE_MISMATCH_FRAC, (frac, mx)
 
 
+def test_window_scores_wide_gqa_group_and_window(P):
+    """kv_group * window = 128 columns: the logits tile needs more than 64 KB of LDS (opt-in attribute path)."""
+    B, Hkv, g, S, w = 1, 1, 4, 1024, 32
+    q, k, _ = make_qkv(B, Hkv * g, S, 128, "bf16", "gauss", 19)
+    k = k[:, ::g].contiguous()
+    kx = k[:, :, None].expand(B, Hkv, g, S, 128).reshape(B, Hkv * g, S, 128)
+    want = O.pool_scores(O.window_scores(q, kx, w), "avgpool", 5)
+    got = P.ops.score_window(q.to(DEV), k.to(DEV), w, "avgpool", 5, kv_group=g).cpu()
+    frac, mx = score_diff(got, want)
+    assert mx <= 1 and frac <= SCORE_MISMATCH_FRAC, (frac, mx)
+
+
 def test_window_scores_32k(P):
     q, k, _ = make_qkv(1, 4, 32768, 128, "bf16", "gauss", 1234)
     want = O.pool_scores(O.window_scores(q, k, 8), "maxpool", 7)
