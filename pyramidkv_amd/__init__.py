@@ -6,6 +6,7 @@ and fails loudly if it has not been built.
 """
 from . import _native  # noqa: F401  (raises ImportError when the HIP extension is missing)
 from . import config, ops  # noqa: F401
+from .cache import DynamicCacheSplitHeadFlatten  # noqa: F401
 from .pyramidkv_utils import (  # noqa: F401
     AdaKVCluster, H2OKVCluster, HeadKVCluster, PyramidKVCluster, SnapKVCluster, StreamingLLMKVCluster,
     init_adakv, init_H2O, init_headkv, init_pyramidkv, init_snapkv, init_StreamingLLM,

@@ -448,6 +448,36 @@ def test_update_flatten_view(P):
     assert torch.equal(got.cpu(), want)
 
 
+def test_flat_cache_decode_steps(P):
+    """AdaKV prefill output -> DynamicCacheSplitHeadFlatten -> three decode appends with the metadata bumps of
+    the reference's forward (llama_model.py:2366-2375): every head's rows stay contiguous and in order."""
+    H, S, w, cap = 8, 2048, 8, 64
+    q, k, v = make_qkv(1, H, S, 128, "fp16", "gauss", 64)
+    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2,
+                        normalize=True, layer_idx=0, num_hidden_layers=32)
+    kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
+    cache = P.DynamicCacheSplitHeadFlatten()
+    cache.update(kf, vf, 0)
+    assert cache.get_seq_length(0) == 1 and cache.get_seq_length(1) == 0 and len(cache) == 1
+    ref_k = [kf.cpu()[int(cl.cu_klen[h]):int(cl.cu_klen[h + 1])] for h in range(H)]
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):
+        nk = torch.randn(1, H, 1, 128, generator=g).to(torch.float16)
+        nv = torch.randn(1, H, 1, 128, generator=g).to(torch.float16)
+        kw = {"head_lens": cl.head_lens, "cu_klen": cl.cu_klen}
+        knew, vnew = cache.update(nk.to(DEV), nv.to(DEV), 0, kw)
+        cl.klen_sum += H                                         # reference forward :2372-2375
+        cl.max_seqlen_k += 1
+        cl.cu_klen += cl.cu_offset
+        cl.head_lens += 1
+        ref_k = [torch.cat([ref_k[h], nk[0, h]], 0) for h in range(H)]
+        assert knew.shape[0] == cl.klen_sum
+        for h in range(H):
+            a, b = int(cl.cu_klen[h]), int(cl.cu_klen[h + 1])
+            assert b - a == int(cl.head_lens[h])
+            assert torch.equal(knew[a:b].cpu(), ref_k[h])
+
+
 # ----------------------------------------------------------------------------------------- golden fixtures
 def test_golden_fixtures_through_hip_path(P):
     """Outputs of the REAL reference (tests/golden, produced on CPU) vs the HIP path on the same inputs.
