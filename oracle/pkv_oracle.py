@@ -345,6 +345,17 @@ def adakv_update_kv(key_states, query_states, value_states, window_size, max_cap
     return kf, vf, meta
 
 
+def headkv_runner_capacity(head_list, num_hidden_layers, num_attention_heads, max_capacity_prompts, head_beta=1.01):
+    """run_longbench.py:227-233, statement for statement (``head_list`` = the parsed score JSON)."""
+    import numpy as np
+    head_score_list = [np.mean(l[1]) for l in head_list.items()]
+    head_score_list = torch.tensor(head_score_list / sum(head_score_list))
+    total_attention = head_score_list.reshape(num_hidden_layers, num_attention_heads)
+    total_pool_capacity = (max_capacity_prompts // head_beta) * num_hidden_layers * num_attention_heads
+    min_num = (max_capacity_prompts - max_capacity_prompts // head_beta)
+    return torch.round(total_attention * total_pool_capacity + min_num).int()
+
+
 def headkv_update_kv(key_states, query_states, value_states, window_size, max_capacity_prompt,
                      kernel_size, pooling, head_capacity, layer_idx, sort_mode="canonical",
                      scale_mode="div"):

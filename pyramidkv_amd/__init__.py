@@ -9,7 +9,7 @@ from . import config, ops  # noqa: F401
 from .cache import DynamicCacheSplitHeadFlatten  # noqa: F401
 from .pyramidkv_utils import (  # noqa: F401
     AdaKVCluster, H2OKVCluster, HeadKVCluster, PyramidKVCluster, SnapKVCluster, StreamingLLMKVCluster,
-    init_adakv, init_H2O, init_headkv, init_pyramidkv, init_snapkv, init_StreamingLLM,
+    headkv_head_capacity, init_adakv, init_H2O, init_headkv, init_pyramidkv, init_snapkv, init_StreamingLLM,
 )
 
 __version__ = "0.1.0"

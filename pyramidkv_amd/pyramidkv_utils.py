@@ -383,3 +383,23 @@ def init_headkv(self):
             window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
             kernel_size=self.config.kernel_size, pooling=self.config.pooling,
             head_capacity=self.config.head_capacity)
+
+
+def headkv_head_capacity(head_scores, num_hidden_layers, num_attention_heads, max_capacity_prompts, head_beta=1.01):
+    """Per-(layer, head) HeadKV budgets from a retrieval/reasoning head-score table (reference runner,
+    run_longbench.py:225-234; the score files are data/heads_score/*.json: ``{"layer-head": [scores...]}``).
+
+    ``head_scores`` is that mapping (insertion order = layer-major, as the runner iterates ``.items()``) or a
+    sequence of per-head score lists.  Arithmetic is IEEE double exactly as the runner's numpy/torch mix:
+    mean per head -> / sequential sum -> x pool + min_num -> round half-to-even -> int32
+    ``[num_hidden_layers, num_attention_heads]`` (what ``config.head_capacity`` holds, :234)."""
+    import numpy as np
+    rows = list(head_scores.values()) if hasattr(head_scores, "values") else list(head_scores)
+    if len(rows) != num_hidden_layers * num_attention_heads:
+        raise ValueError(f"head score table has {len(rows)} heads, model has {num_hidden_layers}x{num_attention_heads}")
+    means = [np.mean(r) for r in rows]                                           # :228
+    share = np.asarray(means, dtype=np.float64) / sum(means)                      # :229 (builtin sum: sequential)
+    pool = (max_capacity_prompts // head_beta) * num_hidden_layers * num_attention_heads   # :231
+    min_num = max_capacity_prompts - max_capacity_prompts // head_beta           # :232
+    cap = np.round(share * pool + min_num).astype(np.int32)                      # :233
+    return torch.from_numpy(cap.reshape(num_hidden_layers, num_attention_heads))

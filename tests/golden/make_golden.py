@@ -142,6 +142,22 @@ def run_case(c):
     return out
 
 
+def head_capacity_fixture():
+    """HeadKV budgets from the reference's own Llama-3 head-score table via the runner's arithmetic
+    (run_longbench.py:225-234 is inline in main(), so it is restated in oracle.headkv_runner_capacity; the fixture
+    pins the per-head means of the real table and the budgets for the runner defaults)."""
+    import json as _json
+    from oracle import pkv_oracle as O
+    path = "/root/reference/data/heads_score/Meta-Llama-3-8B-Instruct_retrieval_reasoning_heads.json"
+    with open(path) as f:
+        head_list = _json.loads(f.readline())
+    out = {"means": np.asarray([np.mean(v) for v in head_list.values()], dtype=np.float64)}
+    for cap in (128, 2048):
+        out[f"cap{cap}"] = O.headkv_runner_capacity(head_list, 32, 32, cap, 1.01).numpy()
+    np.savez_compressed(os.path.join(HERE, "headkv_capacity_llama3.npz"), **out)
+    print("headkv_capacity_llama3", {k: v.shape for k, v in out.items()})
+
+
 def main():
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     index = []
@@ -151,6 +167,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         index.append(dict(name=name, **c))
         print(name, {k: getattr(v, 'shape', v) for k, v in out.items() if k not in ('kc', 'vc')})
+    head_capacity_fixture()
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(dict(torch=torch.__version__, reference="Zefan-Cai/PyramidKV@2024-12-20",
                        cases=index), f, indent=1)

@@ -161,3 +161,24 @@ def test_bf16_scale_by_reciprocal_equals_division_exhaustively():
         b = (x * torch.tensor(rc, dtype=torch.float32)).to(tdt).view(torch.int16)
         same = bool((a == b)[fin].all())
         assert same == expect_equal
+
+
+def test_headkv_capacity_from_head_scores(P):
+    """run_longbench.py:225-234: product helper == runner restatement == fixture made from the reference's
+    Llama-3 head-score table (tests/golden/make_golden.py: head_capacity_fixture)."""
+    import numpy as np
+    from oracle import pkv_oracle as O
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "headkv_capacity_llama3.npz"))
+    means = fx["means"]
+    table = {f"{i // 32}-{i % 32}": [float(m)] for i, m in enumerate(means)}       # one score per head: mean == itself
+    for cap in (128, 2048):
+        got = P.headkv_head_capacity(table, 32, 32, cap, 1.01)
+        assert got.dtype == torch.int32 and tuple(got.shape) == (32, 32)
+        assert np.array_equal(got.numpy(), fx[f"cap{cap}"])
+        assert torch.equal(got, O.headkv_runner_capacity(table, 32, 32, cap, 1.01))
+    rng = np.random.default_rng(3)                                                # ragged synthetic tables, odd geometry
+    table = {f"{l}-{h}": list(rng.random(rng.integers(1, 40)) * (rng.random() < 0.7)) for l in range(5) for h in range(6)}
+    for cap, beta in ((64, 1.01), (512, 1.2), (1024, 2.0), (96, 1.005)):
+        assert torch.equal(P.headkv_head_capacity(table, 5, 6, cap, beta), O.headkv_runner_capacity(table, 5, 6, cap, beta))
+    with pytest.raises(ValueError):
+        P.headkv_head_capacity(table, 5, 7, 64)
