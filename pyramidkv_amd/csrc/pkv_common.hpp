@@ -146,6 +146,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: usable with nontemporal builtins
 
 union U4 {

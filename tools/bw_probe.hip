@@ -40,6 +40,89 @@ __global__ __launch_bounds__(256) void frag_kernel(const uint16_t* __restrict__ 
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
 }
 
+
+// ---- candidate K-stream patterns for the logits kernel (one 256-row tile of 256-B rows per workgroup) ----
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// frag pattern with nontemporal loads
+__global__ __launch_bounds__(256) void frag_nt_kernel(const uint16_t* __restrict__ src, size_t rows, uint32_t* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const size_t tile = blockIdx.x;
+  u32x4 acc = {0, 0, 0, 0};
+  u32x4 v[16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const size_t r = tile * 256 + wave * 64 + t * 16 + li;
+    const uint16_t* row = src + (r < rows ? r : rows - 1) * 128 + lg * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) v[t * 4 + kk] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + kk * 32));
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc ^= v[u];
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+
+// row-major: every wave instruction reads 1 KB contiguous (4 whole rows); optional LDS transpose to the MFMA layout
+template <bool NT, bool LDS>
+__global__ __launch_bounds__(256) void rowmajor_kernel(const uint16_t* __restrict__ src, size_t rows, uint32_t* sink) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[LDS ? 4096 : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const size_t tile = blockIdx.x;
+  u32x4 acc = {0, 0, 0, 0};
+  u32x4 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int rl = 4 * j + lg;                       // row within the wave's 64
+    const size_t r = tile * 256 + wave * 64 + rl;
+    const int c = li ^ (rl & 15);                    // pre-swizzled source chunk -> linear LDS slot li
+    const u32x4* ptr = reinterpret_cast<const u32x4*>(src + (r < rows ? r : rows - 1) * 128) + c;
+    v[j] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
+  }
+  if (LDS) {
+    u32x4* w = lds + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j * 64 + lane] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rl = t * 16 + li;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) v[t * 4 + kk] = w[rl * 16 + ((kk * 4 + lg) ^ (rl & 15))];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc ^= v[u];
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+
+// LDS-direct loads (global_load_lds_dwordx4), AUX = 0 default policy, 2 = nt; then MFMA-layout reads
+template <int AUX>
+__global__ __launch_bounds__(256) void glds_kernel(const uint16_t* __restrict__ src, size_t rows, uint32_t* sink) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[4096];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const size_t tile = blockIdx.x;
+  u32x4* w = lds + wave * 1024;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int rl = 4 * j + lg;
+    const size_t r = tile * 256 + wave * 64 + rl;
+    const int c = li ^ (rl & 15);
+    const u32x4* ptr = reinterpret_cast<const u32x4*>(src + (r < rows ? r : rows - 1) * 128) + c;
+    __builtin_amdgcn_global_load_lds((gptr_t)ptr, (lptr_t)(w + j * 64), 16, 0, AUX);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int rl = t * 16 + li;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc ^= w[rl * 16 + ((kk * 4 + lg) ^ (rl & 15))];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+
 template <int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 * UNROLL + threadIdx.x;
@@ -91,6 +174,20 @@ int main() {
     const size_t nn = rows * 16;
     float o = time_ms([&] { hipLaunchKernelGGL((read_kernel<4, false>), dim3((nn + 1023) / 1024), dim3(256), 0, 0, src, nn, sink); });
     printf(" \"onepass_read_rows%zu_GBps\": %.0f,\n", rows, rows * 256.0 / o / 1e6);
+  }
+  for (size_t rows : {(size_t)32 * 32768, (size_t)4 * 1024 * 1024}) {
+    const dim3 g((rows + 255) / 256), b(256);
+    const uint16_t* s16 = (const uint16_t*)src;
+#define PROBE(name, kern) do { float t_ = time_ms([&] { hipLaunchKernelGGL(kern, g, b, 0, 0, s16, rows, sink); }); \
+    printf(" \"%s_rows%zu_GBps\": %.0f,\n", name, rows, rows * 256.0 / t_ / 1e6); } while (0)
+    PROBE("frag_nt", frag_nt_kernel);
+    PROBE("rowmajor", (rowmajor_kernel<false, false>));
+    PROBE("rowmajor_nt", (rowmajor_kernel<true, false>));
+    PROBE("rowmajor_lds", (rowmajor_kernel<false, true>));
+    PROBE("rowmajor_nt_lds", (rowmajor_kernel<true, true>));
+    PROBE("glds", glds_kernel<0>);
+    PROBE("glds_nt", glds_kernel<2>);
+#undef PROBE
   }
   printf(" \"bytes\": %zu\n}\n", bytes);
   return 0;
