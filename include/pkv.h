@@ -67,9 +67,6 @@ typedef struct pkv_desc {
 int pkv_version(void);
 const char* pkv_strerror(int status);
 int pkv_last_hip_error(void); /* hipError_t of the last PKV_ERR_HIP on this thread */
-/* 1 if a kernel gave up on a device-side wait since the last reset (results of that call are invalid);
-   copies one int from the device: synchronises.  Never set in normal operation. */
-int pkv_async_error(int reset);
 
 /* Bytes of scratch pkv_score_window / pkv_score_h2o / pkv_compress need for `d` (256-B aligned). */
 size_t pkv_workspace_bytes(const pkv_desc* d);
@@ -151,7 +148,7 @@ int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const vo
 /* ---- per-kernel device timing (hipEvent pairs on `stream`), used by bench.py ---- */
 enum pkv_kernel_id {
   PKV_K_LOGITS = 0, PKV_K_FINALIZE = 1, PKV_K_TOPK = 2, PKV_K_GATHER = 3, PKV_K_H2O_STATS = 4,
-  PKV_K_H2O_COLSUM = 5, PKV_K_SORT = 6, PKV_K_BUDGET = 7, PKV_K_SCORE_FUSED = 8, PKV_K_COUNT = 9
+  PKV_K_H2O_COLSUM = 5, PKV_K_SORT = 6, PKV_K_BUDGET = 7, PKV_K_COUNT = 8
 };
 int pkv_prof_enable(int on);                                   /* returns previous state */
 int pkv_prof_read(double* ms_sum, int64_t* launches, int reset); /* arrays of PKV_K_COUNT; syncs events */

@@ -17,7 +17,7 @@ PKV_BF16, PKV_F16 = 0, 1
 POOL = {None: 0, "none": 0, "avgpool": 1, "maxpool": 2}
 REDUCE = {"sum": 0, "mean": 1}
 SCALE = {"div": 0, "rcp": 1}
-KERNEL_NAMES = ["logits", "finalize", "topk", "gather", "h2o_stats", "h2o_colsum", "sort", "budget", "score_fused"]
+KERNEL_NAMES = ["logits", "finalize", "topk", "gather", "h2o_stats", "h2o_colsum", "sort", "budget"]
 
 
 class PkvDesc(C.Structure):
@@ -47,7 +47,6 @@ def _load():
         "pkv_version": (C.c_int, []),
         "pkv_strerror": (C.c_char_p, [C.c_int]),
         "pkv_last_hip_error": (C.c_int, []),
-        "pkv_async_error": (C.c_int, [C.c_int]),
         "pkv_workspace_bytes": (sz, [dp]),
         "pkv_score_window": (C.c_int, [dp, vp, vp, vp, i64, vp, sz, vp]),
         "pkv_score_h2o": (C.c_int, [dp, vp, vp, vp, i64, vp, sz, vp]),

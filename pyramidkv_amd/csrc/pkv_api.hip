@@ -7,7 +7,6 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
-#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -30,12 +29,8 @@ int logits_nt() { static int t = env_int("PKV_LOGITS_NT", 0); return t; }
 // pipelined logits kernel (logits2_kernel): 1 = use it when the column count allows, 0 = one-tile-per-workgroup kernel
 int logits_v2() { static int t = env_int("PKV_LOGITS_V2", 1); return t; }
 int logits_v2_nt() { static int t = env_int("PKV_LOGITS_NT", 1); return t; }
-int logits_v2_wgs() { static int t = env_int("PKV_LOGITS_V2_WGS", 0); return t; }   // target workgroup count, 0 = 4 per CU
-int logits_rowmajor() { static int t = env_int("PKV_LOGITS_ROWMAJOR", 0); return t; }
+int logits_v2_wgs() { static int t = env_int("PKV_LOGITS_V2_WGS", 0); return t; }   // target workgroup count, 0 = 8 per CU
 int finalize_nt() { static int t = env_int("PKV_FINALIZE_NT", 0); return t; }
-// one-launch score path (score_fused_kernel); 0 = the two-kernel path (logits + finalize)
-int score_fused() { static int t = env_int("PKV_SCORE_FUSED", 0); return t; }
-int fused_tiles() { static int t = env_int("PKV_FUSED_TILES", 0); return t; }   // tiles per workgroup, 0 = auto
 int logits_ablate() { static int t = env_int("PKV_LOGITS_ABLATE", 0); return t; }   // measurement only: wrong results
 
 inline int hip_fail(hipError_t e) { g_last_hip = (int)e; return PKV_ERR_HIP; }
@@ -98,7 +93,7 @@ int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true) {
 
 struct WsLayout {
   int Sp, nT, Lp;
-  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_rowstat, off_halo, off_ctr, total;
+  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_rowstat, total;
 };
 
 WsLayout ws_layout(const pkv_desc* d) {
@@ -114,8 +109,6 @@ WsLayout ws_layout(const pkv_desc* d) {
   w.off_idx = o;     o = align_up(o + (size_t)d->B * d->H * (d->topk > 0 ? d->topk : 1) * 4, 256);
   w.off_cmax = o;    o = align_up(o + (size_t)d->B * d->H * (w.Lp / 8) * 2, 256);
   w.off_rowstat = o; o = align_up(o + (size_t)d->B * d->H * d->S * sizeof(float2), 256);   // H2O only
-  w.off_halo = o;    o = align_up(o + rows * (size_t)((d->S + 255) / 256) * 32, 256);   // fused score path: <= one workgroup per tile
-  w.off_ctr = o;     o = align_up(o + (size_t)d->B * d->H * 256, 256);
   w.total = o;
   return w;
 }
@@ -127,70 +120,13 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   lp.logits = ws + L.off_logits;
   lp.partial = reinterpret_cast<float2*>(ws + L.off_partial);
   lp.B = d->B; lp.H = d->H; lp.S = d->S; lp.w = d->window; lp.G = d->kv_group;
-  lp.Sp = L.Sp; lp.nT = L.nT; lp.nst = 0; lp.tile = logits_tile(); lp.nt = logits_nt(); lp.rowmajor = logits_rowmajor(); lp.ablate = logits_ablate(); lp.wgtrace = g_wg_trace;
+  lp.Sp = L.Sp; lp.nT = L.nT; lp.nst = 0; lp.tile = logits_tile(); lp.nt = logits_nt(); lp.ablate = logits_ablate(); lp.wgtrace = g_wg_trace;
   lp.qs_b = d->q_stride[0]; lp.qs_h = d->q_stride[1]; lp.qs_s = d->q_stride[2];
   lp.ks_b = d->k_stride[0]; lp.ks_h = d->k_stride[1]; lp.ks_s = d->k_stride[2];
   lp.scale_mode = d->scale_mode;
   lp.sqrt_d = (float)sqrt((double)d->D);   // math.sqrt(head_dim), cast to the fp32 opmath type
   lp.rcp_sqrt_d = 1.0f / lp.sqrt_d;        // ATen GPU path: a * (1.0f / b)
-  // one launch when the group's logits fit the LDS budget and a whole group can be co-resident
   const int C = d->kv_group * d->window;
-  if (score_fused() && C <= 32 && !lp.ablate && !g_topk_trace) {
-    static std::atomic<uint32_t> g_token{1};
-    static std::mutex cap_mu;
-    static int cap_cache[2][9] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1}};   // [dtype][n], for C <= 8; wider C asks each time
-    const int nT = (d->S + 255) / 256;
-    const int ngroups = d->B * (d->H / d->kv_group);
-    auto capacity = [&](int n) -> int {
-      const size_t lds = fused_lds_bytes(C, n);
-      if (lds > 160 * 1024) return 0;
-      if (C == 8) {
-        std::lock_guard<std::mutex> lk(cap_mu);
-        int& c = cap_cache[d->dtype][n];
-        if (c < 0) c = fused_capacity(d->dtype, 1, lds);
-        return c;
-      }
-      return fused_capacity(d->dtype, (C + 15) / 16, lds);
-    };
-    int n = fused_tiles();
-    if (n < 1 || n > 8) {
-      // smallest n that fits every group in one round; otherwise the largest n whose groups fit at all
-      n = 0;
-      for (int c = 1; c <= 8 && !n; ++c) {
-        const int cap = capacity(c);
-        if ((int64_t)ngroups * ((nT + c - 1) / c) <= cap) n = c;
-      }
-      if (!n) n = 8;
-    }
-    const int cap = capacity(n);
-    const int wph = (nT + n - 1) / n;
-    if (cap >= wph) {
-      FusedParams fp;
-      fp.q = q; fp.k = k; fp.scores = scores; fp.scores_stride = stride;
-      fp.cmax = want_cmax ? ws + L.off_cmax : nullptr; fp.cmax_stride = L.Lp / 8;
-      fp.partial = reinterpret_cast<float2*>(ws + L.off_partial);
-      fp.halo = ws + L.off_halo;
-      fp.counters = reinterpret_cast<unsigned long long*>(ws + L.off_ctr);
-      fp.err = fused_err_ptr();
-      fp.token = g_token.fetch_add(1, std::memory_order_relaxed);
-      fp.B = d->B; fp.H = d->H; fp.S = d->S; fp.w = d->window; fp.G = d->kv_group;
-      fp.nT = nT; fp.n = n; fp.wph = wph;
-      fp.gpr = std::min(ngroups, cap / wph);
-      fp.lrow = n * 256 + 24;
-      fp.qs_b = lp.qs_b; fp.qs_h = lp.qs_h; fp.qs_s = lp.qs_s;
-      fp.ks_b = lp.ks_b; fp.ks_h = lp.ks_h; fp.ks_s = lp.ks_s;
-      fp.scale_mode = lp.scale_mode; fp.sqrt_d = lp.sqrt_d; fp.rcp_sqrt_d = lp.rcp_sqrt_d;
-      fp.pool_kind = d->pool_kind;
-      fp.pool_kernel = d->pool_kind == PKV_POOL_NONE ? 1 : d->pool_kernel;
-      fp.reduce = d->reduce;
-      fp.dbg = g_wg_trace; fp.nowait = env_int("PKV_FUSED_NOWAIT", 0);
-      if (!fp.err) return hip_fail(hipErrorInvalidSymbol);
-      ProfScope ps(PKV_K_SCORE_FUSED, st);
-      hipError_t e = launch_score_fused(d->dtype, fp, fp.gpr * wph, fused_lds_bytes(C, n), st);
-      if (e != hipSuccess) return hip_fail(e);
-      return PKV_OK;
-    }
-  }
   int nT_used = L.nT;
   if (logits_v2() && C <= 32 && !g_wg_trace) {
     static int cus = 0;
@@ -200,7 +136,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     }
     const int sph = (d->S + 127) / 128;                                     // stages per head group
     const int64_t total = (int64_t)d->B * (d->H / d->kv_group) * sph;
-    const int target = logits_v2_wgs() > 0 ? logits_v2_wgs() : 4 * cus;     // one resident generation of workgroups
+    const int target = logits_v2_wgs() > 0 ? logits_v2_wgs() : 8 * cus;     // two resident generations of workgroups (measured best of 3..16 per CU, all within 3 %)
     int nst = (int)((total + target - 1) / target);
     nst = std::max(1, std::min(nst, std::min(sph, 64)));
     lp.nst = nst;
@@ -336,19 +272,6 @@ const char* pkv_strerror(int s) {
 
 int pkv_last_hip_error(void) { return g_last_hip; }
 
-int pkv_async_error(int reset) {
-  int* p = fused_err_ptr();
-  if (!p) return hip_fail(hipErrorInvalidSymbol);
-  int v = 0;
-  hipError_t e = hipMemcpy(&v, p, sizeof(int), hipMemcpyDeviceToHost);
-  if (e != hipSuccess) return hip_fail(e);
-  if (reset && v) {
-    const int z = 0;
-    e = hipMemcpy(p, &z, sizeof(int), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return hip_fail(e);
-  }
-  return v;
-}
 
 size_t pkv_workspace_bytes(const pkv_desc* d) {
   if (!d || d->S < 2 || d->window < 1 || d->window >= d->S || d->B < 1 || d->H < 1) return 0;

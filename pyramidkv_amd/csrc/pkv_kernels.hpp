@@ -15,7 +15,6 @@ struct LogitsParams {
   int Sp, nT;
   int tile;          // keys per workgroup: 128 or 256 (nT = ceil(S / tile))
   int nt;            // nontemporal K loads
-  int rowmajor;      // row-major K stream + LDS transpose (PKV_LOGITS_ROWMAJOR)
   int nst;           // logits2_kernel: 128-key stages per workgroup (nT = chunks per head)
   int ablate;        // 0 = full kernel; 1..3 = measurement-only ablations (PKV_LOGITS_ABLATE)
   int64_t qs_b, qs_h, qs_s;
@@ -36,35 +35,6 @@ struct FinalizeParams {
   unsigned long long* trace;   // debug: phase timestamps of block (0,0) (may be null)
   unsigned long long* wgtrace;
   int nt;                // bit 0: nontemporal logits loads, bit 1: nontemporal score stores (PKV_FINALIZE_NT)
-};
-
-// score_fused_kernel: logits + softmax statistics + window reduce + pooling in ONE launch; the logits never
-// leave the LDS of the workgroup that computed them (pkv_score.hip).
-struct FusedParams {
-  const void* q;
-  const void* k;
-  void* scores;            // [B*H][scores_stride] model dtype
-  int64_t scores_stride;
-  void* cmax;              // [B*H][cmax_stride] (may be null)
-  int64_t cmax_stride;
-  float2* partial;         // [groups][wph][C] per-workgroup (row max, sum exp)
-  void* halo;              // [groups][wph][2][C][8] edge logits handed to the neighbouring workgroups
-  unsigned long long* counters;   // [groups][32] arrival counters (one per 256 B), (launch token << 32 | count)
-  int* err;                // device flag: set when a workgroup gave up waiting for its group
-  uint32_t token;          // unique per launch: stale counter contents never match it
-  int B, H, S, w, G;
-  int nT;                  // 256-key tiles per group
-  int n;                   // tiles per workgroup (<= 8)
-  int wph;                 // workgroups per group = ceil(nT / n)
-  int gpr;                 // groups per round = gridDim.x / wph
-  int lrow;                // LDS row stride in elements = n*256 + 24
-  int64_t qs_b, qs_h, qs_s;
-  int64_t ks_b, ks_h, ks_s;
-  int scale_mode;
-  float sqrt_d, rcp_sqrt_d;
-  int pool_kind, pool_kernel, reduce;
-  unsigned long long* dbg;   // debug: 4 wall-clock stamps per workgroup (start, phase 1 done, group met, end) or null
-  int nowait;                // debug: skip the meeting point (wrong results)
 };
 
 struct TopkParams {
@@ -141,10 +111,6 @@ struct H2OParams {
 hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st);
 hipError_t launch_logits2(int dtype, const LogitsParams& p, hipStream_t st);
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st);
-size_t fused_lds_bytes(int C, int n);
-int fused_capacity(int dtype, int nct, size_t lds);   // co-resident workgroups of score_fused_kernel on this device (0 = error)
-hipError_t launch_score_fused(int dtype, const FusedParams& p, int grid, size_t lds, hipStream_t st);
-int* fused_err_ptr();
 size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out);
 hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st);
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);

@@ -38,7 +38,7 @@ template <> struct Mfma<F16> {
 // never drains while other workgroups are in their MFMA / LDS / store phases.  K is streamed once
 // and never re-read: nontemporal loads (NT) keep it out of the way of the logits in L2.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KPW, bool NT, bool RM = false>
+template <typename T, int KPW, bool NT>
 __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   constexpr int TILE = 4 * KPW;            // keys per workgroup
   constexpr int LROW = TILE + 8;           // LDS row stride in elements (16-B aligned rows, <=2-way write conflicts)
@@ -69,28 +69,6 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const int s_wave = t_idx * TILE + wave * KPW;
   u32x4 kf[NSUB][4];
-  if constexpr (RM) {
-    // Row-major stream: every wave instruction reads 1 KB contiguous = 4 whole K rows (full cache lines), then a
-    // wave-private 16 KB LDS transpose hands each lane its MFMA fragment.  Lane (lg, li) of load j fetches chunk
-    // li ^ (row & 15) of row 4j + lg, so the linear LDS image is XOR-swizzled and both sides are conflict-free.
-    constexpr int NLD = KPW / 4;          // 1-KB load instructions per wave (4 rows each)
-    u32x4* kst = reinterpret_cast<u32x4*>(smem_raw + (size_t)p.G * p.w * LROW * sizeof(uint16_t)) + wave * (KPW * 16);
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int rl = 4 * j + lg;
-      int s = s_wave + rl;
-      s = s < S ? s : S - 1;
-      const u32x4* ptr = reinterpret_cast<const u32x4*>(kbase + (int64_t)s * p.ks_s) + (li ^ (rl & 15));
-      kf[j >> 2][j & 3] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
-    }
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) kst[j * 64 + lane] = kf[j >> 2][j & 3];
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NSUB; ++t)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) kf[t][kk] = kst[(t * 16 + li) * 16 + ((kk * 4 + lg) ^ li)];
-  } else {
 #pragma unroll
   for (int t = 0; t < NSUB; ++t) {
     int s = s_wave + t * 16 + li;
@@ -101,7 +79,6 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
       const u32x4* ptr = reinterpret_cast<const u32x4*>(row + kk * 32);
       kf[t][kk] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
     }
-  }
   }
 
   if (p.ablate == 3) {   // measurement aid: K loads only
@@ -395,427 +372,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 #undef PKV_FSTAMP
 }
 
-// ------------------------------------------------------------------------------------------------
-// score_fused_kernel: reference pyramidkv_utils.py:317-333 in one launch.
-//
-// A workgroup owns n (<= 4) consecutive 256-key tiles of one (batch, kv-head group).  Phase 1 is the
-// logits kernel above, except that the rounded logits stay in this workgroup's LDS ([C][lrow], 8 halo
-// columns each side) and only the per-tile (max, sum exp) partials go to memory.  The workgroups of
-// a group then meet at a counter (all of them are co-resident: the grid never exceeds the device's
-// capacity for this kernel, launch_score_fused), read every tile's partials -> M, 1/Z per window row,
-// and phase 2 is finalize_kernel on the LDS copy: fp32 softmax -> dtype, row reduce -> dtype, pool,
-// chunk maxima.  Pooling needs the un-pooled score of <= 8 positions owned by each neighbour: their
-// logits (16 B per column and side) are exchanged through `halo` before the meeting point.
-// Saves the logits round trip through HBM (S*w*e written and read per head) and one launch.
-// ------------------------------------------------------------------------------------------------
-__device__ int g_fused_err = 0;
-
-// Device-scope exchange without cache-wide fences: the few words the workgroups of a group hand each other
-// are written and read as relaxed agent-scope atomics (sc1: written through / fetched from the point where
-// the 8 XCD L2s agree), ordered by an explicit s_waitcnt before the arrival counter is bumped.  An
-// agent-scope release/acquire fence would write back and invalidate a whole L2 per wave (buffer_wbl2 /
-// buffer_inv) - measured 15x slower for this kernel.
-__device__ __forceinline__ void st_agent_u64(void* p, unsigned long long v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long ld_agent_u64(const void* p) {
-  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ld_agent_f2(const float2* p) {
-  const unsigned long long u = ld_agent_u64(p);
-  return make_float2(__uint_as_float((uint32_t)u), __uint_as_float((uint32_t)(u >> 32)));
-}
-constexpr unsigned long long FUSED_SPIN_LIMIT = 200000000ull;   // 2 s of the 100 MHz wall clock
-
 // (m, l) of two disjoint key sets -> (max, sum exp relative to it); -inf-safe
 __device__ __forceinline__ void stat_merge(float& m, float& l, float m2, float l2) {
   const float M = fmaxf(m, m2);
   const float Ms = (M == -INFINITY) ? 0.f : M;
   l = l * pkv_exp(m - Ms) + l2 * pkv_exp(m2 - Ms);
   m = M;
-}
-
-template <typename T, int NCT>
-__global__ __launch_bounds__(256) void score_fused_kernel(FusedParams p) {
-  constexpr int TILE = 256, HT = 128;   // HT keys per pipeline stage: 32 per wave = 2 MFMA subtiles
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int w = p.w, C = p.G * w, S = p.S, L = S - w, lrow = p.lrow;
-  uint16_t* tile = reinterpret_cast<uint16_t*>(smem_raw);                       // [C][lrow]
-  uint16_t* sc = tile + C * lrow;                                               // [n*256 + 16] un-pooled scores
-  float* rowM = reinterpret_cast<float*>(sc + p.n * TILE + 16);                 // [C]
-  float* rowRZ = rowM + C;                                                      // [C]
-  float2* wst = reinterpret_cast<float2*>(rowRZ + C);                           // [4][C] per-wave (max, sum exp)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lg = lane >> 4;
-  const int HG = p.H / p.G;
-  const int ngroups = p.B * HG;
-  const int gi = blockIdx.x / p.wph;
-  const int ci = blockIdx.x - gi * p.wph;
-  const float fmin_v = Elem<T>::finfo_min();
-
-  if (p.dbg && tid == 0) p.dbg[4 * blockIdx.x] = wall_clock64();
-  for (int grp = gi; grp < ngroups; grp += p.gpr) {
-    const int b = grp / HG;
-    const int hk = grp - b * HG;
-    const int h0 = hk * p.G;
-    const int t0 = ci * p.n;
-    const int nt = min(p.n, p.nT - t0);             // tiles of this workgroup (>= 1)
-    const int start = t0 * TILE;                    // first key
-    const int nh = 2 * nt;                          // pipeline stages (even: loads are issued unconditionally, see below)
-    const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
-    const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b;
-    float2* part = p.partial + (int64_t)grp * p.wph * C;
-
-    // ---------------- phase 1: logits into LDS, running (max, sum exp) per column in registers ----------------
-    u32x4 qf[NCT][4];
-#pragma unroll
-    for (int n = 0; n < NCT; ++n) {
-      const int c = n * 16 + li;
-      if (c < C) {
-        const int hh = h0 + c / w;
-        const int rr = c - (c / w) * w;
-        const uint16_t* qrow = qb + (int64_t)hh * p.qs_h + (int64_t)(L + rr) * p.qs_s + lg * 8;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[n][kk] = *reinterpret_cast<const u32x4*>(qrow + kk * 32);
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[n][kk] = u32x4{0, 0, 0, 0};
-      }
-    }
-    float m_run[NCT], l_run[NCT];
-#pragma unroll
-    for (int n = 0; n < NCT; ++n) { m_run[n] = -INFINITY; l_run[n] = 0.f; }
-
-    auto load_stage = [&](u32x4 (&kf)[2][4], int h) {
-      const int s_wave = start + h * HT + wave * 32;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        int s = s_wave + t * 16 + li;
-        s = s < S ? s : S - 1;            // clamp: stay in bounds; keys past S are masked out of the statistics
-        const uint16_t* row = kbase + (int64_t)s * p.ks_s + lg * 8;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) kf[t][kk] = *reinterpret_cast<const u32x4*>(row + kk * 32);
-      }
-    };
-    auto compute_stage = [&](u32x4 (&kf)[2][4], int h) {
-      const int kw = h * HT + wave * 32;                     // first key of this wave's stage, relative to `start`
-      const bool edge = start + (h + 1) * HT > L;            // stage touches the window corner and/or keys >= S
-#pragma unroll
-      for (int n = 0; n < NCT; ++n) {
-        const int c = n * 16 + li;
-        const int rr_c = c % w;
-        float xs[8];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(kf[t][kk], qf[n][kk], acc);
-          const int key0 = kw + t * 16 + lg * 4;
-          uint32_t p01 = round_pack2<T>(acc[0], acc[1]);                               // matmul output dtype (:317)
-          uint32_t p23 = round_pack2<T>(acc[2], acc[3]);
-          float x0 = Elem<T>::to_f32((uint16_t)(p01 & 0xffffu)), x1 = Elem<T>::to_f32((uint16_t)(p01 >> 16));
-          float x2 = Elem<T>::to_f32((uint16_t)(p23 & 0xffffu)), x3 = Elem<T>::to_f32((uint16_t)(p23 >> 16));
-          x0 = scale_logit<T>(x0, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);              // "/ math.sqrt(head_dim)" (:317)
-          x1 = scale_logit<T>(x1, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);
-          x2 = scale_logit<T>(x2, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);
-          x3 = scale_logit<T>(x3, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);
-          p01 = round_pack2<T>(x0, x1);
-          p23 = round_pack2<T>(x2, x3);
-          uint16_t o[4] = {(uint16_t)(p01 & 0xffffu), (uint16_t)(p01 >> 16), (uint16_t)(p23 & 0xffffu), (uint16_t)(p23 >> 16)};
-          if (edge) {                                                                  // strict upper corner (:318-324)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int s = start + key0 + r;
-              if (s >= L && (s - L) > rr_c) o[r] = Elem<T>::from_f32(Elem<T>::to_f32(o[r]) + fmin_v);
-            }
-            p01 = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-            p23 = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-          }
-          if (c < C) *reinterpret_cast<uint2*>(tile + c * lrow + 8 + key0) = make_uint2(p01, p23);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float x = Elem<T>::to_f32(o[r]);
-            xs[t * 4 + r] = (edge && start + key0 + r >= S) ? -INFINITY : x;
-          }
-        }
-        float m_loc = xs[0];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) m_loc = fmaxf(m_loc, xs[i]);
-        const float m_new = fmaxf(m_run[n], m_loc);
-        const float ms = (m_new == -INFINITY) ? 0.f : m_new;
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sum += pkv_exp(xs[i] - ms);
-        l_run[n] = l_run[n] * pkv_exp(m_run[n] - ms) + sum;
-        m_run[n] = m_new;
-      }
-    };
-
-    {
-      u32x4 ka[2][4], kb[2][4];
-      // Two stages per trip; the next stage's loads fly during this one's MFMA / epilogue.  Every load is issued
-      // unconditionally (a branch around a load makes the compiler wait for ALL outstanding loads at the join):
-      // the last trip re-requests its own second stage, an L2 hit.
-      load_stage(ka, 0);
-      for (int h = 0; h < nh; h += 2) {
-        load_stage(kb, h + 1);
-        compute_stage(ka, h);
-        load_stage(ka, min(h + 2, nh - 1));
-        compute_stage(kb, h + 1);
-      }
-    }
-    // per column: merge the 4 key-group lanes, then the 4 waves, one partial per (workgroup, column)
-#pragma unroll
-    for (int n = 0; n < NCT; ++n) {
-      float m = m_run[n], l = l_run[n];
-      stat_merge(m, l, __shfl_xor(m, 16, 64), __shfl_xor(l, 16, 64));
-      stat_merge(m, l, __shfl_xor(m, 32, 64), __shfl_xor(l, 32, 64));
-      const int c = n * 16 + li;
-      if (lg == 0 && c < C) wst[wave * C + c] = make_float2(m, l);
-    }
-    __syncthreads();
-    if (tid < C) {
-      float2 a = wst[tid];
-#pragma unroll
-      for (int wv = 1; wv < 4; ++wv) { const float2 o = wst[wv * C + tid]; stat_merge(a.x, a.y, o.x, o.y); }
-      st_agent_u64(part + (int64_t)ci * C + tid, (unsigned long long)__float_as_uint(a.x) | ((unsigned long long)__float_as_uint(a.y) << 32));
-    }
-    // edge logits for the neighbours: first 8 keys (side 0) and last 8 keys of the last tile (side 1)
-    if (tid >= 64 && tid < 64 + 2 * C) {
-      const int c = (tid - 64) >> 1, side = tid & 1;
-      const uint4 v = *reinterpret_cast<const uint4*>(tile + c * lrow + 8 + (side ? nt * TILE - 8 : 0));
-      unsigned long long* hp = reinterpret_cast<unsigned long long*>(p.halo) + ((((int64_t)grp * p.wph + ci) * 2 + side) * C + c) * 2;
-      st_agent_u64(hp, (unsigned long long)v.x | ((unsigned long long)v.y << 32));
-      st_agent_u64(hp + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32));
-    }
-    if (p.dbg && tid == 0 && grp == gi) p.dbg[4 * blockIdx.x + 1] = wall_clock64();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every thread: its partial / halo stores have completed ...
-    __syncthreads();                                   // ... before thread 0 announces the workgroup
-    if (tid == 0 && !p.nowait) {
-      unsigned long long* ctr = p.counters + (int64_t)grp * 32;     // one counter per 256 B: pollers of different groups never share a line
-      const unsigned long long tokhi = (unsigned long long)p.token << 32;
-      unsigned long long cur = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long nxt;
-      while (true) {   // whatever the workspace held before (garbage, an older launch) does not carry this token
-        nxt = ((cur >> 32) == p.token) ? cur + 1 : (tokhi | 1ull);
-        if (__hip_atomic_compare_exchange_strong(ctr, &cur, nxt, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      }
-      const unsigned long long want = tokhi | (unsigned long long)p.wph;
-      if (nxt != want) {                                             // the last workgroup to arrive does not wait
-        const unsigned long long t_begin = wall_clock64();
-        while (true) {
-          __builtin_amdgcn_s_sleep(24);                              // ~0.7 us between polls: the pollers must not crowd the K stream
-          if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) break;
-          if (wall_clock64() - t_begin > FUSED_SPIN_LIMIT) { atomicExch(p.err, 1); break; }   // never hang the device
-        }
-      }
-    }
-    __syncthreads();
-    if (p.dbg && tid == 0 && grp == gi) p.dbg[4 * blockIdx.x + 2] = wall_clock64();
-
-    // ---------------- phase 2: statistics of the whole row, halo import ----------------
-    if (tid >= 64 && tid < 64 + 2 * C) {
-      const int c = (tid - 64) >> 1, side = tid & 1;
-      const int nb = side ? ci + 1 : ci - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (nb >= 0 && nb < p.wph) {
-        const unsigned long long* hp = reinterpret_cast<const unsigned long long*>(p.halo) + ((((int64_t)grp * p.wph + nb) * 2 + (side ^ 1)) * C + c) * 2;
-        const unsigned long long lo = ld_agent_u64(hp), hi = ld_agent_u64(hp + 1);
-        v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-      }
-      *reinterpret_cast<uint4*>(tile + c * lrow + (side ? 8 + nt * TILE : 0)) = v;
-    }
-    {
-      const int LPC = C <= 8 ? 32 : 8;               // lanes per column
-      const int sub = tid & (LPC - 1);
-      const int cpp = 256 / LPC;                      // columns per pass
-      for (int c0 = 0; c0 < C; c0 += cpp) {
-        const int c = c0 + tid / LPC;
-        const bool live = c < C;
-        const float2* pr = part + (live ? c : 0);
-        float m = -INFINITY, z = 0.f;
-        for (int tb = 0; tb < p.wph; tb += 4 * LPC) {
-          float2 pv[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int t = tb + sub + LPC * i;
-            pv[i] = ld_agent_f2(pr + (int64_t)(t < p.wph ? t : p.wph - 1) * C);
-            if (t >= p.wph) pv[i] = make_float2(-INFINITY, 0.f);
-          }
-          float mc = fmaxf(fmaxf(pv[0].x, pv[1].x), fmaxf(pv[2].x, pv[3].x));
-          for (int o = LPC / 2; o > 0; o >>= 1) mc = fmaxf(mc, __shfl_xor(mc, o, 64));
-          const float mn = fmaxf(m, mc);
-          const float ms = (mn == -INFINITY) ? 0.f : mn;
-          float zc = 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) zc += pv[i].y * pkv_exp(pv[i].x - ms);
-          for (int o = LPC / 2; o > 0; o >>= 1) zc += __shfl_xor(zc, o, 64);
-          z = z * pkv_exp(m - ms) + zc;
-          m = mn;
-        }
-        if (live && sub == 0) { rowM[c] = m; rowRZ[c] = 1.0f / z; }   // ATen CPU softmax: x * (1 / sum)
-      }
-    }
-    __syncthreads();
-    const uint16_t pad = (p.pool_kind == 2) ? Elem<T>::neg_inf() : (uint16_t)0;
-    const int half = p.pool_kernel >> 1;
-    const int ngr = (nt * TILE + 16) >> 2;            // groups of 4 positions incl. both halos
-    for (int g = 0; g < p.G; ++g) {
-      const int bh = b * p.H + h0 + g;
-      const uint16_t* trow = tile + g * w * lrow;
-      // un-pooled score of every position in [start - 8, start + nt*256 + 8)
-      for (int gidx = tid; gidx < ngr; gidx += 256) {
-        const int s0 = start - 8 + gidx * 4;
-        uint16_t ov[4];
-        if (s0 + 3 >= 0 && s0 < L) {
-          float acc[4] = {0.f, 0.f, 0.f, 0.f};
-          for (int rb = 0; rb < w; rb += 8) {
-            uint2 u[8];
-            float M[8], RZ[8], wt[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int r = rb + j < w ? rb + j : w - 1;
-              u[j] = *reinterpret_cast<const uint2*>(trow + r * lrow + gidx * 4);
-              M[j] = rowM[g * w + r];
-              RZ[j] = rowRZ[g * w + r];
-              wt[j] = rb + j < w ? 1.0f : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const uint16_t h4[4] = {(uint16_t)(u[j].x & 0xffffu), (uint16_t)(u[j].x >> 16),
-                                      (uint16_t)(u[j].y & 0xffffu), (uint16_t)(u[j].y >> 16)};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float pr = pkv_exp(Elem<T>::to_f32(h4[e]) - M[j]) * RZ[j];        // fp32 softmax (:326)
-                acc[e] += wt[j] * Elem<T>::to_f32(Elem<T>::from_f32(pr));               // .to(dtype); fp32 row accumulate (:327)
-              }
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = (p.reduce == 1) ? (acc[e] / (float)w) : acc[e];             // mean (:661) or sum (:327)
-            ov[e] = (s0 + e >= 0 && s0 + e < L) ? Elem<T>::from_f32(v) : pad;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ov[e] = pad;
-        }
-        uint2 pk;
-        pk.x = (uint32_t)ov[0] | ((uint32_t)ov[1] << 16);
-        pk.y = (uint32_t)ov[2] | ((uint32_t)ov[3] << 16);
-        *reinterpret_cast<uint2*>(sc + gidx * 4) = pk;
-      }
-      __syncthreads();
-      // pooling, chunk maxima, store: own positions only
-      for (int t4 = tid; t4 < nt * (TILE / 4); t4 += 256) {
-        const int s0 = start + t4 * 4;
-        const bool writer = s0 < L;
-        uint16_t res[4];
-        float v[20];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-          const uint2 t = *reinterpret_cast<const uint2*>(sc + t4 * 4 + i * 4);       // sc index = position - start + 8
-          v[i * 4 + 0] = Elem<T>::to_f32((uint16_t)(t.x & 0xffffu));
-          v[i * 4 + 1] = Elem<T>::to_f32((uint16_t)(t.x >> 16));
-          v[i * 4 + 2] = Elem<T>::to_f32((uint16_t)(t.y & 0xffffu));
-          v[i * 4 + 3] = Elem<T>::to_f32((uint16_t)(t.y >> 16));
-        }
-        if (p.pool_kind == 0) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) res[e] = Elem<T>::from_f32(v[8 + e]);
-        } else if (p.pool_kind == 2) {                                                 // max_pool1d, -inf padding (:331)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int j = -8; j <= 8; ++j)
-              if (j >= -half && j <= half) m = fmaxf(m, v[8 + e + j]);
-            res[e] = Elem<T>::from_f32(m);
-          }
-        } else {                                                                       // avg_pool1d, zero padding, / kernel (:329)
-          const float ks = (float)p.pool_kernel;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float sum = 0.f;
-#pragma unroll
-            for (int j = -8; j <= 8; ++j)
-              if (j >= -half && j <= half) sum += v[8 + e + j];
-            res[e] = Elem<T>::from_f32(sum / ks);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (s0 + e >= L) res[e] = pad;
-        if (p.cmax) {
-          float m4 = -INFINITY;
-          uint16_t b4 = Elem<T>::neg_inf();
-          if (writer) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x = Elem<T>::to_f32(res[e]);
-              if (s0 + e < L && x > m4) { m4 = x; b4 = res[e]; }
-            }
-          }
-          const float mo = __shfl_xor(m4, 1, 64);
-          const uint32_t bo = __shfl_xor((uint32_t)b4, 1, 64);
-          if (writer && !(tid & 1))
-            reinterpret_cast<uint16_t*>(p.cmax)[(int64_t)bh * p.cmax_stride + (s0 >> 3)] = (mo > m4) ? (uint16_t)bo : b4;
-        }
-        if (writer) {
-          uint2 ro;
-          ro.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
-          ro.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride + s0) = ro;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (p.dbg && tid == 0) p.dbg[4 * blockIdx.x + 3] = wall_clock64();
-}
-
-size_t fused_lds_bytes(int C, int n) {
-  const size_t lrow = (size_t)n * 256 + 24;
-  return (size_t)C * lrow * 2 + ((size_t)n * 256 + 16) * 2 + (size_t)C * 8 + (size_t)C * 32;
-}
-
-int fused_capacity(int dtype, int nct, size_t lds) {
-  int dev = 0, cus = 0, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  hipError_t e;
-#define PKV_OCC(TT, NCT)                                                                                                  \
-  do {                                                                                                                    \
-    const void* fn = reinterpret_cast<const void*>(score_fused_kernel<TT, NCT>);                                          \
-    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0; \
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_fused_kernel<TT, NCT>, 256, lds);                     \
-  } while (0)
-  if (dtype == 0) { if (nct == 1) PKV_OCC(BF16, 1); else PKV_OCC(BF16, 2); }
-  else            { if (nct == 1) PKV_OCC(F16, 1); else PKV_OCC(F16, 2); }
-#undef PKV_OCC
-  if (e != hipSuccess) return 0;
-  return per_cu * cus;
-}
-
-int* fused_err_ptr() {
-  int* p = nullptr;
-  if (hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_fused_err)) != hipSuccess) return nullptr;
-  return p;
-}
-
-hipError_t launch_score_fused(int dtype, const FusedParams& p, int grid, size_t lds, hipStream_t st) {
-  const int nct = (p.G * p.w + 15) / 16;
-  if (dtype == 0) {
-    if (nct == 1) hipLaunchKernelGGL((score_fused_kernel<BF16, 1>), dim3(grid), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((score_fused_kernel<BF16, 2>), dim3(grid), dim3(256), lds, st, p);
-  } else {
-    if (nct == 1) hipLaunchKernelGGL((score_fused_kernel<F16, 1>), dim3(grid), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((score_fused_kernel<F16, 2>), dim3(grid), dim3(256), lds, st, p);
-  }
-  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1013,26 +575,17 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
   const int C = p.G * p.w;
   dim3 grid(p.nT, p.B * (p.H / p.G));
   const int tile = p.tile;
-  const bool rm = p.rowmajor && C <= 64;
-  const size_t lds = (size_t)C * (tile + 8) * sizeof(uint16_t) + (rm ? (size_t)tile * 256 : 0);
-#define PKV_LAUNCH(TT, KPW, ...)                                                                                        \
+  const size_t lds = (size_t)C * (tile + 8) * sizeof(uint16_t);
+#define PKV_LAUNCH(TT, KPW, NT)                                                                                         \
   do {                                                                                                                 \
     if (lds > 64 * 1024) {  /* wide GQA groups x wide windows: opt in to more than 64 KB of dynamic LDS */           \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(logits_kernel<TT, KPW, __VA_ARGS__>),         \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(logits_kernel<TT, KPW, NT>),                  \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
       if (e_ != hipSuccess) return e_;                                                                                \
     }                                                                                                                  \
-    hipLaunchKernelGGL((logits_kernel<TT, KPW, __VA_ARGS__>), grid, dim3(256), lds, st, p);                           \
+    hipLaunchKernelGGL((logits_kernel<TT, KPW, NT>), grid, dim3(256), lds, st, p);                                    \
   } while (0)
-  if (rm) {
-    if (tile == 128) {
-      if (dtype == 0) { if (p.nt) PKV_LAUNCH(BF16, 32, true, true); else PKV_LAUNCH(BF16, 32, false, true); }
-      else            { if (p.nt) PKV_LAUNCH(F16, 32, true, true); else PKV_LAUNCH(F16, 32, false, true); }
-    } else {
-      if (dtype == 0) { if (p.nt) PKV_LAUNCH(BF16, 64, true, true); else PKV_LAUNCH(BF16, 64, false, true); }
-      else            { if (p.nt) PKV_LAUNCH(F16, 64, true, true); else PKV_LAUNCH(F16, 64, false, true); }
-    }
-  } else if (dtype == 0) {
+  if (dtype == 0) {
     if (tile == 128) { if (p.nt) PKV_LAUNCH(BF16, 32, true); else PKV_LAUNCH(BF16, 32, false); }
     else             { if (p.nt) PKV_LAUNCH(BF16, 64, true); else PKV_LAUNCH(BF16, 64, false); }
   } else {

@@ -609,7 +609,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
 // (key<<16 | index) ping-pong through the sorted_idx output buffer, which every thread re-reads into
 // registers before anything is overwritten.
 // ------------------------------------------------------------------------------------------------
-constexpr int SR_MAX_L = 32768;
 
 // match-any: the set of valid lanes of the wave that hold the same 8-bit digit
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
