@@ -17,6 +17,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         if "pkv::" not in name:
             continue
         short = name.split("pkv::")[1].split("_kernel")[0]
+        if short == "logits2":      # the pipelined variant of the logits kernel reports under the same profiler id
+            short = "logits"
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 1",
        "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), KiB -> bytes", "kernels": {}}
