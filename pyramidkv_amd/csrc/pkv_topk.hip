@@ -22,7 +22,7 @@ constexpr int TK_CNT_WORDS = 256 * 32;   // counters[bin][lane&31], lo16 = lanes
 constexpr int TK_RANK_MAX = 512;         // k <= this: order by rank counting (O(k^2), no barriers)
 constexpr int TK_RADIX_MAX = 4096;       // k <= this (and LDS allows): stable 2-pass LSD radix ordering
 constexpr int TK_FAST_K = 512;           // k <= this: try the chunk-maxima prefilter first
-constexpr int TK_FAST_C = 576;           // at most this many candidates: rank them directly (O(C^2))
+constexpr int TK_FAST_C = 448;           // at most this many candidates: rank them directly (O(C^2)); above, the exact select inside the list is cheaper (measured crossover ~440)
 constexpr int TK_MID_C = 4096;           // at most this many: exact select inside the candidate list first
 constexpr size_t TK_LDS_LIMIT = 160 * 1024;
 

@@ -478,6 +478,32 @@ def test_flat_cache_decode_steps(P):
             assert torch.equal(knew[a:b].cpu(), ref_k[h])
 
 
+def test_update_kv_is_graph_capturable(P):
+    """libpkv never synchronises, allocates or touches the default stream: a whole update_kv can be captured in a
+    HIP graph and replayed on new contents of the same buffers (what a serving stack does with its prefill step)."""
+    q, k, v = (t.to(DEV) for t in make_qkv(1, 8, 4096, 128, "bf16", "gauss", 90))
+    cl = P.SnapKVCluster(window_size=8, max_capacity_prompt=128, kernel_size=7, pooling="maxpool")
+    kc_ref, vc_ref = cl.update_kv(k, q, v, None, 1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm the per-stream workspace before capture
+        cl.update_kv(k, q, v, None, 1)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        kc, vc = cl.update_kv(k, q, v, None, 1)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
+    q2, k2, v2 = (t.to(DEV) for t in make_qkv(1, 8, 4096, 128, "bf16", "gauss", 91))
+    kc2_ref, vc2_ref = cl.update_kv(k2, q2, v2, None, 1)
+    kc2_ref, vc2_ref = kc2_ref.clone(), vc2_ref.clone()
+    q.copy_(q2); k.copy_(k2); v.copy_(v2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(kc, kc2_ref) and torch.equal(vc, vc2_ref)
+
+
 # ----------------------------------------------------------------------------------------- golden fixtures
 def test_golden_fixtures_through_hip_path(P):
     """Outputs of the REAL reference (tests/golden, produced on CPU) vs the HIP path on the same inputs.
