@@ -33,6 +33,8 @@ _METHODS: Dict[str, tuple] = {
 }
 # the module whose init_* functions build the clusters; tests swap in an oracle-backed stand-in on CPU
 _cluster_module = _utils
+# hand K/V to update_kv BEFORE repeat_kv when the cluster accepts it (pyramidkv_amd's do); False = the reference's order
+skip_repeat_kv = True
 
 
 def _repeat_kv(x: torch.Tensor, n_rep: int) -> torch.Tensor:
@@ -43,9 +45,14 @@ def _repeat_kv(x: torch.Tensor, n_rep: int) -> torch.Tensor:
 
 
 def _attend(module, q, k, v, attention_mask, is_prefill):
-    """Attention over already-expanded K/V (no second repeat_kv).  eager = the reference's matmul /
-    fp32 softmax / matmul (llama_model.py:174-183); otherwise PyTorch SDPA."""
+    """Attention over K/V with H heads (no second repeat_kv) or H/g heads (un-expanded: SDPA's grouped-query
+    path, expanded views for eager).  eager = the reference's matmul / fp32 softmax / matmul
+    (llama_model.py:174-183); otherwise PyTorch SDPA."""
     q_len, kv_len = q.shape[-2], k.shape[-2]
+    gqa = k.shape[1] != q.shape[1]
+    if gqa and getattr(module.config, "_attn_implementation", "sdpa") == "eager":
+        k, v = _repeat_kv(k, q.shape[1] // k.shape[1]), _repeat_kv(v, q.shape[1] // v.shape[1])
+        gqa = False
     mask = None
     if attention_mask is not None and q_len > 1:
         mask = attention_mask[:, :, :, :kv_len]          # reference :176-178
@@ -59,7 +66,7 @@ def _attend(module, q, k, v, attention_mask, is_prefill):
         w = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
         out = torch.matmul(w, v)
     else:
-        out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, is_causal=causal, scale=module.scaling)
+        out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, is_causal=causal, scale=module.scaling, enable_gqa=gqa)
     return out.transpose(1, 2).contiguous()
 
 
@@ -74,8 +81,6 @@ def _make_forward(method: str, apply_rotary_pos_emb: Callable):
         v = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
         cos, sin = position_embeddings
         q, k = apply_rotary_pos_emb(q, k, cos, sin)
-        k = _repeat_kv(k, self.num_key_value_groups)                      # llama_model.py:158
-        v = _repeat_kv(v, self.num_key_value_groups)                      # llama_model.py:159
         is_prefill = True
         if past_key_values is not None:
             is_prefill = past_key_values.get_seq_length(self.layer_idx) == 0   # == (key_len == kv_seq_len), :165
@@ -85,9 +90,16 @@ def _make_forward(method: str, apply_rotary_pos_emb: Callable):
                     init(self, self.config.num_hidden_layers)             # llama_model.py:101
                 else:
                     init(self)
+                # The reference materialises repeat_kv first (:158-159) - g copies of K and V, more bytes than the
+                # whole eviction step moves.  Clusters that say so take the H/g heads as they are (same result).
+                if not (skip_repeat_kv and getattr(self.kv_cluster, "accepts_unexpanded_kv", False)):
+                    k = _repeat_kv(k, self.num_key_value_groups)          # llama_model.py:158
+                    v = _repeat_kv(v, self.num_key_value_groups)          # llama_model.py:159
                 kc, vc = self.kv_cluster.update_kv(k, q, v, attention_mask, self.num_key_value_groups)   # :167
                 past_key_values.update(kc, vc, self.layer_idx)            # :168 (the prompt attends to the full K/V)
             else:
+                k = _repeat_kv(k, self.num_key_value_groups)              # one token: the cache holds all H heads
+                v = _repeat_kv(v, self.num_key_value_groups)
                 k, v = past_key_values.update(k, v, self.layer_idx)       # :171
         attn = _attend(self, q, k, v, attention_mask, is_prefill)
         attn = attn.reshape(*input_shape, -1).contiguous()

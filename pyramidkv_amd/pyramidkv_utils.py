@@ -40,6 +40,25 @@ def _dedup_view(t: torch.Tensor, g: int) -> torch.Tensor:
     return t if g == 1 else t[:, ::g]
 
 
+def _repeat_kv(t: torch.Tensor, g: int) -> torch.Tensor:
+    """reference pyramidkv_utils.py:109-117."""
+    if g == 1:
+        return t
+    b, h, s, d = t.shape
+    return t[:, :, None, :, :].expand(b, h, g, s, d).reshape(b, h * g, s, d)
+
+
+def _unexpanded_group(key_states, query_states) -> int:
+    """K/V may be handed over BEFORE repeat_kv ([B, H/g, S, D] next to Q [B, H, S, D]); the
+    kernels then read every KV head once per group instead of g materialised copies.  Returns g (1 = already expanded)."""
+    hq, hk = query_states.shape[1], key_states.shape[1]
+    if hk == hq:
+        return 1
+    if hk == 0 or hq % hk:
+        raise ValueError(f"{hk} key/value heads do not divide {hq} query heads")
+    return hq // hk
+
+
 class _WindowPolicy:
     """Shared body of SnapKV / PyramidKV / H2O: score -> top-k -> gather in one C call."""
 
@@ -47,11 +66,24 @@ class _WindowPolicy:
     kernel_size: int
     pooling: str
 
+    accepts_unexpanded_kv = True      # update_kv also takes K/V with H/g heads (before repeat_kv)
+
     def _compress(self, key_states, query_states, value_states, k, num_key_value_groups, h2o=False):
+        gu = _unexpanded_group(key_states, query_states)
+        if gu > 1:
+            return ops.compress(query_states, key_states, value_states, self.window_size, k, self.pooling,
+                                self.kernel_size, scale_mode=_cfg.scale_mode, kv_group=gu, h2o=h2o)
         g = _kv_group(num_key_value_groups, query_states.shape[1])
         return ops.compress(query_states, _dedup_view(key_states, g), _dedup_view(value_states, g),
                             self.window_size, k, self.pooling, self.kernel_size,
                             scale_mode=_cfg.scale_mode, kv_group=g, h2o=h2o)
+
+    @staticmethod
+    def _passthrough(key_states, query_states, value_states):
+        """S < max_capacity_prompt: the reference returns its inputs (:219,:315); un-expanded inputs come back as the
+        repeat_kv tensors the reference would have been handed."""
+        g = _unexpanded_group(key_states, query_states)
+        return _repeat_kv(key_states, g), _repeat_kv(value_states, g)
 
 
 class PyramidKVCluster(_WindowPolicy):
@@ -98,7 +130,7 @@ class PyramidKVCluster(_WindowPolicy):
         q_len = query_states.shape[-2]
         branch, k = self.layer_budget(q_len)
         if branch == "passthrough":
-            return key_states, value_states                                          # :219 (same objects)
+            return self._passthrough(key_states, query_states, value_states)        # :219 (same objects)
         if self.pooling not in ('avgpool', 'maxpool'):
             raise ValueError('Pooling method not supported')                         # :237
         _check_merge(self.merge)
@@ -131,7 +163,7 @@ class SnapKVCluster(_WindowPolicy):
         assert key_states.shape[-2] == query_states.shape[-2]                       # :309
         q_len = query_states.shape[-2]
         if q_len < self.max_capacity_prompt:                                        # :314
-            return key_states, value_states
+            return self._passthrough(key_states, query_states, value_states)
         if self.pooling not in ('avgpool', 'maxpool'):
             raise ValueError('Pooling method not supported')                         # :333
         _check_merge(self.merge)
@@ -156,7 +188,7 @@ class H2OKVCluster(_WindowPolicy):
         assert key_states.shape[-2] == query_states.shape[-2]                       # :536
         q_len = query_states.shape[-2]
         if q_len < self.max_capacity_prompt:                                        # :541
-            return key_states, value_states
+            return self._passthrough(key_states, query_states, value_states)
         _check_merge(self.merge)
         return self._compress(key_states, query_states, value_states,
                               self.max_capacity_prompt - self.window_size, num_key_value_groups, h2o=True)
@@ -164,6 +196,8 @@ class H2OKVCluster(_WindowPolicy):
 
 class StreamingLLMKVCluster:
     """reference pyramidkv_utils.py:578-620: attention sinks 0..cap-w-1 + the last w tokens."""
+
+    accepts_unexpanded_kv = True
 
     def __init__(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None):
         self.window_size = window_size
@@ -178,11 +212,13 @@ class StreamingLLMKVCluster:
     def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
         assert key_states.shape[-2] == query_states.shape[-2]                       # :598
         q_len = query_states.shape[-2]
+        g = _unexpanded_group(key_states, query_states)
         if q_len < self.max_capacity_prompt:                                        # :603
-            return key_states, value_states
+            return _repeat_kv(key_states, g), _repeat_kv(value_states, g)
         _check_merge(self.merge)
-        return ops.gather_streaming(key_states, value_states, self.max_capacity_prompt - self.window_size,
-                                    self.window_size)
+        kc, vc = ops.gather_streaming(key_states, value_states, self.max_capacity_prompt - self.window_size,
+                                      self.window_size)
+        return _repeat_kv(kc, g), _repeat_kv(vc, g)       # every head of a group keeps the same tokens
 
 
 class _FlatPolicy:

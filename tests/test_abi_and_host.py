@@ -182,3 +182,20 @@ def test_headkv_capacity_from_head_scores(P):
         assert torch.equal(P.headkv_head_capacity(table, 5, 6, cap, beta), O.headkv_runner_capacity(table, 5, 6, cap, beta))
     with pytest.raises(ValueError):
         P.headkv_head_capacity(table, 5, 7, 64)
+
+
+def test_passthrough_with_unexpanded_kv_returns_repeat_kv(P):
+    """K/V handed over before repeat_kv (H/g heads): the S < max_capacity_prompt early return gives back what the
+    reference would have been handed - the repeat_kv tensors (pyramidkv_utils.py:109-117, :219, :315)."""
+    q, k, v = make_qkv(1, 8, 40, 128, "bf16", "gauss", 4)
+    k_un, v_un = k[:, ::4].contiguous(), v[:, ::4].contiguous()          # 2 KV heads, groups of 4
+    want_k = k_un[:, :, None].expand(1, 2, 4, 40, 128).reshape(1, 8, 40, 128)
+    want_v = v_un[:, :, None].expand(1, 2, 4, 40, 128).reshape(1, 8, 40, 128)
+    for cl in (P.SnapKVCluster(window_size=8, max_capacity_prompt=64), P.H2OKVCluster(window_size=8, max_capacity_prompt=64),
+               P.StreamingLLMKVCluster(window_size=8, max_capacity_prompt=64),
+               P.PyramidKVCluster(num_hidden_layers=4, window_size=8, max_capacity_prompt=64, layer_idx=1)):
+        assert cl.accepts_unexpanded_kv
+        kc, vc = cl.update_kv(k_un, q, v_un, None, 4)
+        assert torch.equal(kc, want_k) and torch.equal(vc, want_v)
+    with pytest.raises(ValueError):
+        P.SnapKVCluster(window_size=8, max_capacity_prompt=64).update_kv(k[:, :3], q, v[:, :3], None, 4)

@@ -624,6 +624,41 @@ def test_replace_llama_end_to_end_on_gpu(P):
         mp.restore()
 
 
+@pytest.mark.parametrize("method", ["pyramidkv", "snapkv", "streamingllm", "h2o"])
+def test_adapter_unexpanded_kv_equals_reference_order(P, method):
+    """The adapter hands K/V to update_kv before repeat_kv (skip_repeat_kv, H/g heads read once per group); the caches
+    must be bit-identical to those of the reference's order (repeat_kv first, llama_model.py:158-168)."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from pyramidkv_amd import monkeypatch as mp
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=97, hidden_size=1024, intermediate_size=512, num_hidden_layers=2, num_attention_heads=8,
+                      num_key_value_heads=2, head_dim=128, max_position_embeddings=8192)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(DEV).eval()
+    S, cap, w = 1024, 96, 8
+    ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(3)).to(DEV)
+    caches = {}
+    try:
+        mp.replace_llama(method)
+        for layer in model.model.layers:
+            c = layer.self_attn.config
+            c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = w, cap, 7, "maxpool", None
+        for skip in (True, False):
+            mp.skip_repeat_kv = skip
+            with torch.no_grad():
+                out = model(ids, past_key_values=transformers.DynamicCache(config=cfg), use_cache=True)
+                nxt = model(out.logits[:, -1:].argmax(-1), past_key_values=out.past_key_values, use_cache=True,
+                            position_ids=torch.tensor([[S]], device=DEV), cache_position=torch.tensor([S], device=DEV))
+            caches[skip] = ([(l.keys.clone(), l.values.clone()) for l in out.past_key_values.layers], nxt.logits.clone())
+    finally:
+        mp.skip_repeat_kv = True
+        mp.restore()
+    for (ka, va), (kb, vb) in zip(caches[True][0], caches[False][0]):
+        assert ka.shape == kb.shape and ka.shape[1] == 8
+        assert torch.equal(ka, kb) and torch.equal(va, vb)
+    assert torch.allclose(caches[True][1].float(), caches[False][1].float(), atol=2e-2, rtol=2e-2)
+
+
 # ----------------------------------------------------------------------------------------- full-size checks
 @pytest.mark.parametrize("B,cap", [(2, 128), (1, 2048), (2, 4096)])
 def test_full_size_selection_properties(P, B, cap):

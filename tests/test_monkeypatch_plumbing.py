@@ -28,7 +28,27 @@ class _OracleCluster:
         return O.streamingllm_update_kv(k, q, v, c.window_size, c.max_capacity_prompt)
 
 
-def _oracle_module():
+class _OracleClusterUnexpanded(_OracleCluster):
+    """Stand-in for the product clusters' contract: also takes K/V with H/g heads (before repeat_kv)."""
+    accepts_unexpanded_kv = True
+
+    def update_kv(self, k, q, v, mask, groups):
+        g = q.shape[1] // k.shape[1]
+        if g > 1:
+            b, h, s, d = k.shape
+            k = k[:, :, None].expand(b, h, g, s, d).reshape(b, h * g, s, d)
+            v = v[:, :, None].expand(b, h, g, s, d).reshape(b, h * g, s, d)
+        return super().update_kv(k, q, v, mask, groups)
+
+
+def _oracle_module(cls=None):
+    if cls is not None:
+        m = types.SimpleNamespace()
+        m.init_pyramidkv = lambda self, n: setattr(self, "kv_cluster", cls("pyramidkv", self.config, self.layer_idx, n))
+        m.init_snapkv = lambda self: setattr(self, "kv_cluster", cls("snapkv", self.config, self.layer_idx, 0))
+        m.init_H2O = lambda self: setattr(self, "kv_cluster", cls("h2o", self.config, self.layer_idx, 0))
+        m.init_StreamingLLM = lambda self: setattr(self, "kv_cluster", cls("streamingllm", self.config, self.layer_idx, 0))
+        return m
     m = types.SimpleNamespace()
     m.init_pyramidkv = lambda self, n: setattr(self, "kv_cluster", _OracleCluster("pyramidkv", self.config, self.layer_idx, n))
     m.init_snapkv = lambda self: setattr(self, "kv_cluster", _OracleCluster("snapkv", self.config, self.layer_idx, 0))
@@ -140,3 +160,31 @@ def test_hf_generate_runs_on_compacted_cache(patched, method):
         assert lens == [48 + 4] * model.config.num_hidden_layers
     else:
         assert lens == [O.pyramid_budget(48, 8, model.config.num_hidden_layers, i, S)[1] + 8 + 4 for i in range(model.config.num_hidden_layers)]
+
+
+@pytest.mark.parametrize("method", ["pyramidkv", "streamingllm"])
+def test_unexpanded_kv_branch_gives_the_same_cache(patched, method):
+    """Clusters that accept K/V before repeat_kv get them un-expanded; cache contents and logits equal the
+    reference order (expanded first)."""
+    from transformers import DynamicCache
+    model = _tiny("llama")
+    S = 160
+    ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(5))
+    res = {}
+    for cls in (_OracleCluster, _OracleClusterUnexpanded):
+        patched._cluster_module = _oracle_module(cls)
+        patched.replace_llama(method)
+        for layer in model.model.layers:
+            if hasattr(layer.self_attn, "kv_cluster"):
+                del layer.self_attn.kv_cluster
+            c = layer.self_attn.config
+            c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = 8, 64, 7, "maxpool", None
+        cache = DynamicCache(config=model.config)
+        with torch.no_grad():
+            out = model(ids, past_key_values=cache, use_cache=True)
+        res[cls.__name__] = (out.logits, [(l.keys.clone(), l.values.clone()) for l in cache.layers])
+        assert isinstance(model.model.layers[0].self_attn.kv_cluster, cls)
+    a, b = res["_OracleCluster"], res["_OracleClusterUnexpanded"]
+    assert torch.allclose(a[0], b[0], atol=1e-5, rtol=1e-5)
+    for (ka, va), (kb, vb) in zip(a[1], b[1]):
+        assert torch.equal(ka, kb) and torch.equal(va, vb)
