@@ -21,6 +21,7 @@ from oracle import pkv_oracle as O
 pytestmark = pytest.mark.gpu
 
 SCORE_MISMATCH_FRAC = 2e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda"
 REPORT = {}
 
@@ -502,6 +503,19 @@ def test_update_kv_is_graph_capturable(P):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(kc, kc2_ref) and torch.equal(vc, vc2_ref)
+
+
+def test_c_host_without_python_bindings(P):
+    """examples/host_cabi.cpp: a C++ host using only include/pkv.h and the HIP runtime (no torch, no ctypes) runs
+    SnapKV update_kv through the C ABI and verifies selection order, dominance, gather and the error convention."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "host_cabi")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host_cabi: ok" in r.stdout
 
 
 # ----------------------------------------------------------------------------------------- golden fixtures
