@@ -91,6 +91,14 @@ int pkv_topk(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scor
              int64_t scores_stride, const int32_t* k_per_row, int32_t* idx_out, int64_t idx_stride,
              pkv_stream_t stream);
 
+/* Rows longer than one workgroup's LDS (L > 57 344 keys; k <= 32 768): the same selection through per-segment
+ * top-k + a top-k over the segment winners; needs pkv_topk_workspace_bytes() of 16-B aligned scratch (0 for rows
+ * pkv_topk handles itself; k_per_row is not supported on long rows). */
+size_t pkv_topk_workspace_bytes(int32_t rows, int32_t L, int32_t k);
+int pkv_topk_ws(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores,
+                int64_t scores_stride, const int32_t* k_per_row, int32_t* idx_out, int64_t idx_stride,
+                void* ws, size_t ws_bytes, pkv_stream_t stream);
+
 /* Gather-compaction (pyramidkv_utils.py:335,341-346): K_out/V_out[b,h] = rows idx[b,h,0..k) of
  * K/V[b,h,:S-w] followed by the w window rows S-w..S-1.  Outputs are contiguous [B,H,k+w,D].
  * idx: int32 [B*H][idx_stride].  d->topk = k.  Uses d->k_stride/v_stride/kv_group. */

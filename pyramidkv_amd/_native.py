@@ -51,6 +51,8 @@ def _load():
         "pkv_score_window": (C.c_int, [dp, vp, vp, vp, i64, vp, sz, vp]),
         "pkv_score_h2o": (C.c_int, [dp, vp, vp, vp, i64, vp, sz, vp]),
         "pkv_topk": (C.c_int, [i32, i32, i32, i32, vp, i64, vp, vp, i64, vp]),
+        "pkv_topk_workspace_bytes": (sz, [i32, i32, i32]),
+        "pkv_topk_ws": (C.c_int, [i32, i32, i32, i32, vp, i64, vp, vp, i64, vp, sz, vp]),
         "pkv_gather_compact": (C.c_int, [dp, vp, vp, vp, i64, vp, vp, vp]),
         "pkv_gather_streaming": (C.c_int, [dp, vp, vp, vp, vp, vp]),
         "pkv_compress": (C.c_int, [dp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

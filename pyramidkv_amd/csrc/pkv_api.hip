@@ -91,9 +91,11 @@ int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true) {
   return PKV_OK;
 }
 
+size_t topk_tmp_bytes(int rows, int L, int k);
+
 struct WsLayout {
   int Sp, nT, Lp;
-  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_rowstat, total;
+  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_tk, tk_bytes, off_rowstat, total;
 };
 
 WsLayout ws_layout(const pkv_desc* d) {
@@ -108,6 +110,8 @@ WsLayout ws_layout(const pkv_desc* d) {
   w.off_scores = o;  o = align_up(o + (size_t)d->B * d->H * w.Lp * 2, 256);
   w.off_idx = o;     o = align_up(o + (size_t)d->B * d->H * (d->topk > 0 ? d->topk : 1) * 4, 256);
   w.off_cmax = o;    o = align_up(o + (size_t)d->B * d->H * (w.Lp / 8) * 2, 256);
+  w.tk_bytes = d->topk > 0 ? topk_tmp_bytes(d->B * d->H, d->S - d->window, d->topk) : 0;      // long-row top-k scratch (0 up to 57 344 keys)
+  w.off_tk = o;      o = align_up(o + w.tk_bytes, 256);
   w.off_rowstat = o; o = align_up(o + (size_t)d->B * d->H * d->S * sizeof(float2), 256);   // H2O only
   w.total = o;
   return w;
@@ -193,20 +197,60 @@ int do_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores, 
   return PKV_OK;
 }
 
+constexpr int TK_SEG = 32768;     // segment length of the long-row path (one workgroup's LDS holds up to 57 344 keys)
+
+bool topk_fits(int L, int k) {
+  int Lw, kpad;
+  const size_t lds = topk_lds_bytes(L, k, &Lw, &kpad);
+  return lds <= 160 * 1024 && 16 * (size_t)Lw <= 65536;
+}
+
+// scratch of the long-row path: segment winners [rows][nseg*k] int32, their scores, positions of the final winners
+size_t topk_tmp_bytes(int rows, int L, int k) {
+  if (L < 1 || k < 1 || rows < 1 || topk_fits(L, k)) return 0;
+  const size_t nseg = ((size_t)L + TK_SEG - 1) / TK_SEG;
+  const size_t cand = nseg * (size_t)k, cstride = align_up(cand, 8);
+  return align_up((size_t)rows * cand * 4, 256) + align_up((size_t)rows * cstride * 2, 256) + align_up((size_t)rows * k * 4, 256);
+}
+
 int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t stride, const int32_t* kpr,
-            int32_t* idx, int64_t idx_stride, hipStream_t st, const void* cmax = nullptr, int64_t cmax_stride = 0) {
+            int32_t* idx, int64_t idx_stride, hipStream_t st, const void* cmax = nullptr, int64_t cmax_stride = 0,
+            void* tmp = nullptr, size_t tmp_bytes = 0) {
   if (L < 1 || k < 1 || k > L || rows < 1) return PKV_ERR_SHAPE;
   TopkParams tp;
   tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
   tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace; tp.wgtrace = g_wg_trace; tp.cmax = cmax; tp.cmax_stride = cmax_stride;
-  const size_t lds = topk_lds_bytes(L, k, &tp.Lw, &tp.kpad);
-  if (lds > 160 * 1024 || 16 * (size_t)tp.Lw > 65536) return PKV_ERR_UNSUPPORTED;
-  {
+  tp.nseg = 1; tp.seg_len = 0;
+  auto launch = [&](int nrows, int Lwg) -> int {     // Lwg = keys one workgroup handles
+    const size_t lds = topk_lds_bytes(Lwg, tp.k, &tp.Lw, &tp.kpad);
+    if (lds > 160 * 1024 || 16 * (size_t)tp.Lw > 65536) return PKV_ERR_UNSUPPORTED;
     const size_t xw = (size_t)(tp.kpad > 8192 ? tp.kpad : 8192);
     tp.dual = lds >= (size_t)2 * 16 * tp.Lw + 4 * xw + 4 * 256 + 4 * 64 + 4 * 8192 ? 1 : 0;
-  }
-  ProfScope ps(PKV_K_TOPK, st);
-  hipError_t e = launch_topk(dtype, rows, tp, lds, st);
+    ProfScope ps(PKV_K_TOPK, st);
+    hipError_t e = launch_topk(dtype, nrows, tp, lds, st);
+    return e == hipSuccess ? PKV_OK : hip_fail(e);
+  };
+  if (topk_fits(L, k)) return launch(rows, L);
+  // long rows: top-k of every 32k segment (row-global indices, canonical order inside the segment), then the top-k of
+  // the nseg*k winners.  The candidate list is segment-major, so position order == index order among equal scores and
+  // the second selection reproduces (value desc, index asc) of the whole row.
+  const size_t need = topk_tmp_bytes(rows, L, k);
+  if (!tmp || tmp_bytes < need || kpr || k > TK_SEG || (reinterpret_cast<uintptr_t>(tmp) & 15)) return PKV_ERR_UNSUPPORTED;
+  const int nseg = (L + TK_SEG - 1) / TK_SEG;
+  const int64_t cand = (int64_t)nseg * k, cstride = (int64_t)align_up((size_t)cand, 8);
+  if (!topk_fits((int)cand, k) || (int64_t)rows * nseg > 0x7fffffff) return PKV_ERR_UNSUPPORTED;
+  char* t8 = static_cast<char*>(tmp);
+  int32_t* cand_idx = reinterpret_cast<int32_t*>(t8);
+  void* cand_score = t8 + align_up((size_t)rows * cand * 4, 256);
+  int32_t* pos = reinterpret_cast<int32_t*>(t8 + align_up((size_t)rows * cand * 4, 256) + align_up((size_t)rows * cstride * 2, 256));
+  tp.nseg = nseg; tp.seg_len = TK_SEG; tp.idx_out = cand_idx; tp.idx_stride = k;
+  int rc = launch(rows * nseg, TK_SEG);
+  if (rc) return rc;
+  hipError_t e = launch_topk_merge_prep(dtype, rows, L, k, nseg, TK_SEG, scores, stride, cand_idx, cand_score, cstride, st);
+  if (e != hipSuccess) return hip_fail(e);
+  rc = do_topk(dtype, rows, (int)cand, k, cand_score, cstride, nullptr, pos, k, st);
+  if (rc) return rc;
+  e = launch_topk_merge_finish(rows, k, cand_idx, cand, pos, idx, idx_stride, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }
 
@@ -243,7 +287,8 @@ int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, c
   if (rc) return rc;
   int32_t* idx = idx_out ? idx_out : reinterpret_cast<int32_t*>(w + L.off_idx);
   rc = do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx, d->topk, st,
-               cm ? w + L.off_cmax : nullptr, L.Lp / 8);
+               cm ? w + L.off_cmax : nullptr, L.Lp / 8,
+               w + L.off_tk, L.tk_bytes);
   if (rc) return rc;
   GatherParams g = make_gather(d, k, v, k_out, v_out);
   g.idx = idx; g.idx_stride = d->topk;
@@ -308,6 +353,19 @@ int pkv_topk(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scor
   if (!scores || !idx_out) return PKV_ERR_NULL;
   if (scores_stride < L || idx_stride < k) return PKV_ERR_SHAPE;
   return do_topk(dtype, rows, L, k, scores, scores_stride, k_per_row, idx_out, idx_stride, static_cast<hipStream_t>(stream));
+}
+
+size_t pkv_topk_workspace_bytes(int32_t rows, int32_t L, int32_t k) { return topk_tmp_bytes(rows, L, k); }
+
+int pkv_topk_ws(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores, int64_t scores_stride,
+                const int32_t* k_per_row, int32_t* idx_out, int64_t idx_stride, void* ws, size_t ws_bytes,
+                pkv_stream_t stream) {
+  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (!scores || !idx_out) return PKV_ERR_NULL;
+  if (scores_stride < L || idx_stride < k) return PKV_ERR_SHAPE;
+  if (topk_tmp_bytes(rows, L, k) > 0 && (!ws || ws_bytes < topk_tmp_bytes(rows, L, k))) return PKV_ERR_WORKSPACE;
+  return do_topk(dtype, rows, L, k, scores, scores_stride, k_per_row, idx_out, idx_stride, static_cast<hipStream_t>(stream),
+                 nullptr, 0, ws, ws_bytes);
 }
 
 int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx,

@@ -51,6 +51,8 @@ struct TopkParams {
   int Lw;                // keys per wave (multiple of 512)
   int kpad;              // words reserved for the selection list (see topk_lds_bytes)
   int dual;              // second 32 KB counter / radix scratch region present in LDS
+  int nseg, seg_len;     // long rows: workgroup r handles segment r % nseg (seg_len keys) of row r / nseg and writes
+                         // row-global indices to idx_out row r; L stays the full row length.  nseg <= 1: off
 };
 
 struct SortParams {
@@ -113,6 +115,11 @@ hipError_t launch_logits2(int dtype, const LogitsParams& p, hipStream_t st);
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st);
 size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out);
 hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st);
+// long-row merge helpers: candidate scores of the per-segment winners, and the final index look-up
+hipError_t launch_topk_merge_prep(int dtype, int rows, int L, int k, int nseg, int seg_len, const void* scores, int64_t scores_stride,
+                                  const int32_t* cand_idx, void* cand_score, int64_t cand_stride, hipStream_t st);
+hipError_t launch_topk_merge_finish(int rows, int k, const int32_t* cand_idx, int64_t cand_stride, const int32_t* pos, int32_t* idx_out,
+                                    int64_t idx_stride, hipStream_t st);
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);
 hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);

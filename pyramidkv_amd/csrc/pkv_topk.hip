@@ -147,8 +147,14 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int row = blockIdx.x;
-  const int L = p.L;
+  const int vrow = blockIdx.x;         // output row
+  int row = vrow, seg_off = 0, Lrow = p.L;
+  if (p.nseg > 1) {                    // long rows: this workgroup owns one segment, see TopkParams::nseg
+    row = vrow / p.nseg;
+    seg_off = (vrow - row * p.nseg) * p.seg_len;
+    Lrow = min(p.seg_len, p.L - seg_off);
+  }
+  const int L = Lrow;
   int k = p.k;
   if (p.k_per_row) { const int kr = p.k_per_row[row]; k = kr < k ? kr : k; }
   if (k <= 0) return;
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   uint32_t* X2 = miscu + 64;                                               // only if p.dual
   const bool dual = p.dual != 0;
 
-  const uint16_t* src = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)row * p.scores_stride;
+  const uint16_t* src = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)row * p.scores_stride + seg_off;
   const bool vec_ok = ((p.scores_stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
   const uint32_t inc = lane < 32 ? 1u : 65536u;
   const int cslot = lane & 31;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     }
   };
   if (use_cmax) {
-    const uint16_t* cmp = reinterpret_cast<const uint16_t*>(p.cmax) + (int64_t)row * p.cmax_stride;
+    const uint16_t* cmp = reinterpret_cast<const uint16_t*>(p.cmax) + (int64_t)row * p.cmax_stride + (seg_off >> 3);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j < niter) {
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       }
       for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
       if (g == 0 && ci < n && rank < k)
-        p.idx_out[(int64_t)row * p.idx_stride + rank] = (int32_t)(0xffffu - (mine & 0xffffu));
+        p.idx_out[(int64_t)vrow * p.idx_stride + rank] = seg_off + (int32_t)(0xffffu - (mine & 0xffffu));
     };
     if (C <= TK_FAST_C || (C <= TK_MID_C && dual)) {
       uint32_t* cand = X;                       // the stage-1 counters in X are no longer needed
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   __syncthreads();
   PKV_STAMP(5);
 
-  int32_t* out = p.idx_out + (int64_t)row * p.idx_stride;
+  int32_t* out = p.idx_out + (int64_t)vrow * p.idx_stride;
   if (k <= TK_RANK_MAX) {
     // rank by counting: composites are unique, so ranks form a permutation of 0..k-1
     if (tid < k) {
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
                 (a1.z > mine) + (a1.w > mine) + (a2.x > mine) + (a2.y > mine) + (a2.z > mine) + (a2.w > mine) +
                 (a3.x > mine) + (a3.y > mine) + (a3.z > mine) + (a3.w > mine);
       }
-      out[rank] = (int32_t)(0xffffu - (mine & 0xffffu));
+      out[rank] = seg_off + (int32_t)(0xffffu - (mine & 0xffffu));
     }
   } else if (k <= TK_RADIX_MAX && dual) {
     // the compacted list is index-ordered within equal keys, so a STABLE sort by key alone gives the
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     const int ept = (k + TK_THREADS - 1) / TK_THREADS;
     radix_pass(sel, sel2, table, hist, k, ept, 0, tid);
     radix_pass(sel2, sel, table, hist, k, ept, 1, tid);
-    for (int i = tid; i < k; i += TK_THREADS) out[i] = (int32_t)(0xffffu - (sel[i] & 0xffffu));
+    for (int i = tid; i < k; i += TK_THREADS) out[i] = seg_off + (int32_t)(0xffffu - (sel[i] & 0xffffu));
   } else {
     // bitonic network, descending (kpad is a power of two here)
     int kp2 = 1;
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         __syncthreads();
       }
     }
-    for (int i = tid; i < k; i += TK_THREADS) out[i] = (int32_t)(0xffffu - (sel[i] & 0xffffu));
+    for (int i = tid; i < k; i += TK_THREADS) out[i] = seg_off + (int32_t)(0xffffu - (sel[i] & 0xffffu));
   }
   PKV_STAMP(6);
   if (p.wgtrace && tid == 0) { p.wgtrace[2 * (131072 + row)] = t_start; p.wgtrace[2 * (131072 + row) + 1] = wall_clock64(); }
@@ -709,6 +715,45 @@ hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hip
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(rows), dim3(TK_THREADS), lds, st, p);
+  return hipGetLastError();
+}
+
+// ---- long rows (L beyond one workgroup's LDS): per-segment top-k, then a top-k over the segment winners ----
+// cand_score[row][t] = score of candidate t = (segment t / k, rank t % k), the lowest value where that segment holds
+// fewer than k keys (only the last one can: the filler sits at the end of the list and loses every tie by position).
+template <typename T>
+__global__ __launch_bounds__(256) void topk_merge_prep_kernel(int L, int k, int nseg, int seg_len, const uint16_t* scores, int64_t scores_stride,
+                                                              const int32_t* cand_idx, uint16_t* cand_score, int64_t cand_stride) {
+  const int row = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nseg * k) return;
+  const int seg = t / k, j = t - seg * k;
+  const int lseg = min(seg_len, L - seg * seg_len);
+  uint16_t v = Elem<T>::neg_inf();
+  if (j < min(k, lseg)) v = scores[(int64_t)row * scores_stride + cand_idx[(int64_t)row * nseg * k + t]];
+  cand_score[(int64_t)row * cand_stride + t] = v;
+}
+
+__global__ __launch_bounds__(256) void topk_merge_finish_kernel(int k, const int32_t* cand_idx, int64_t cand_stride, const int32_t* pos,
+                                                                int32_t* idx_out, int64_t idx_stride) {
+  const int row = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < k) idx_out[(int64_t)row * idx_stride + j] = cand_idx[(int64_t)row * cand_stride + pos[(int64_t)row * k + j]];
+}
+
+hipError_t launch_topk_merge_prep(int dtype, int rows, int L, int k, int nseg, int seg_len, const void* scores, int64_t scores_stride,
+                                  const int32_t* cand_idx, void* cand_score, int64_t cand_stride, hipStream_t st) {
+  dim3 grid((nseg * k + 255) / 256, rows);
+  if (dtype == 0) hipLaunchKernelGGL(topk_merge_prep_kernel<BF16>, grid, dim3(256), 0, st, L, k, nseg, seg_len, static_cast<const uint16_t*>(scores),
+                                     scores_stride, cand_idx, static_cast<uint16_t*>(cand_score), cand_stride);
+  else hipLaunchKernelGGL(topk_merge_prep_kernel<F16>, grid, dim3(256), 0, st, L, k, nseg, seg_len, static_cast<const uint16_t*>(scores),
+                          scores_stride, cand_idx, static_cast<uint16_t*>(cand_score), cand_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_topk_merge_finish(int rows, int k, const int32_t* cand_idx, int64_t cand_stride, const int32_t* pos, int32_t* idx_out,
+                                    int64_t idx_stride, hipStream_t st) {
+  hipLaunchKernelGGL(topk_merge_finish_kernel, dim3((k + 255) / 256, rows), dim3(256), 0, st, k, cand_idx, cand_stride, pos, idx_out, idx_stride);
   return hipGetLastError();
 }
 

@@ -116,8 +116,14 @@ def topk(scores: torch.Tensor, k: int) -> torch.Tensor:
         stride = L
     out = torch.empty(*lead, k, dtype=torch.int32, device=scores.device)
     with torch.cuda.device(scores.device):
-        N.check(N.lib.pkv_topk(N.dtype_code(scores.dtype), rows, L, k, scores.data_ptr(), stride, None,
-                               out.data_ptr(), k, N.stream_ptr()), "pkv_topk")
+        nb = N.lib.pkv_topk_workspace_bytes(rows, L, k)          # > 0 only for rows beyond one workgroup's LDS
+        if nb:
+            ws = workspace(nb, scores.device)
+            N.check(N.lib.pkv_topk_ws(N.dtype_code(scores.dtype), rows, L, k, scores.data_ptr(), stride, None,
+                                      out.data_ptr(), k, ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_topk_ws")
+        else:
+            N.check(N.lib.pkv_topk(N.dtype_code(scores.dtype), rows, L, k, scores.data_ptr(), stride, None,
+                                   out.data_ptr(), k, N.stream_ptr()), "pkv_topk")
     return out
 
 

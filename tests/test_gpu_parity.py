@@ -673,6 +673,33 @@ def test_adapter_unexpanded_kv_equals_reference_order(P, method):
     assert torch.allclose(caches[True][1].float(), caches[False][1].float(), atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("L,k", [(65536, 120), (131064, 2040), (100003, 17), (57345, 4096), (200000, 300)])
+def test_topk_long_rows_vs_oracle(P, L, k):
+    """Rows beyond one workgroup's LDS (57 344 keys): per-segment top-k + top-k of the winners is bit-identical to the
+    canonical top-k of the whole row, ties included (scores quantised so that ties cross segment boundaries)."""
+    g = torch.Generator().manual_seed(L + k)
+    s = (torch.rand(3, L, generator=g) * 37).floor().div(64).to(torch.bfloat16)         # 37 distinct values: heavy ties
+    s[1] = torch.randn(L, generator=g).to(torch.bfloat16)
+    s[2, : L // 2] = 0.5                                                                 # plateau across segments
+    got = P.ops.topk(s.to(DEV), k).cpu().long()
+    want = O.topk_canonical(s, k)
+    assert torch.equal(got, want)
+
+
+def test_compress_long_sequence_selection_properties(P):
+    """S = 131072 (L > one top-k workgroup): update_kv end to end, checked by size-independent properties."""
+    B, H, S, w, kk = 1, 2, 131072, 8, 120
+    g = torch.Generator(device=DEV).manual_seed(11)
+    q, k, v = (torch.randn(B, H, S, 128, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
+    kc, vc, idx = P.ops.compress(q, k, v, w, kk, "maxpool", 7, return_indices=True)
+    s = P.ops.score_window(q, k, w, "maxpool", 7)
+    want = O.topk_canonical(s.cpu(), kk)
+    assert torch.equal(idx.cpu().long(), want)
+    ref_k = torch.cat([torch.gather(k[:, :, :-w], 2, idx.long()[..., None].expand(-1, -1, -1, 128)), k[:, :, -w:]], 2)
+    ref_v = torch.cat([torch.gather(v[:, :, :-w], 2, idx.long()[..., None].expand(-1, -1, -1, 128)), v[:, :, -w:]], 2)
+    assert torch.equal(kc, ref_k) and torch.equal(vc, ref_v)
+
+
 # ----------------------------------------------------------------------------------------- full-size checks
 @pytest.mark.parametrize("B,cap", [(2, 128), (1, 2048), (2, 4096)])
 def test_full_size_selection_properties(P, B, cap):
