@@ -220,9 +220,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         cm[j] = cmp[c < nch ? c : 0];
       }
     }
-  } else {
-    load_all();
   }
+  // the whole row goes in flight now in every path: with the prefilter only the chunks reaching x* are looked at
+  // later, but fetching them after x* is known would put a second cold round trip (~2.5 us) on the critical path
+  load_all();
   for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
   __syncthreads();
   if (p.trace && tid == 0 && row == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[7] = (unsigned long long)clock64(); }
@@ -287,15 +288,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     PKV_STAMP(2);
     const uint32_t xstar = (fb1 << 8) | (uint32_t)misc[2];
     if (use_cmax) {
-      // only chunks whose maximum reaches x* can hold candidates: fetch just those (16 B each)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j < niter) {
-          const int base = wave * Lw + j * 512 + lane * 8;
-          raw[j].v = make_uint4(0, 0, 0, 0);
-          if (gm[j] >= xstar) raw[j].v = *reinterpret_cast<const uint4*>(src + base);
-        }
-      }
+      // only chunks whose maximum reaches x* can hold candidates (their keys arrived with the first round trip)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (j < niter) {
@@ -379,69 +372,25 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         PKV_STAMP(5);
         rank_store(cand, (int)C);
       } else {
-        // 1024 < C <= 4096 candidates: exact radix select INSIDE the candidate list (<= 4 keys per thread
-        // and pass), index-ordered compaction of the k winners, then rank them.
+        // 448 < C <= 4096 candidates, in index order: a STABLE sort by key alone is the canonical order, and
+        // its first k entries are the selection - two LSD radix passes (match-any ballots, no atomics) replace
+        // a two-level select inside the list + compaction + ranking (measured 13k -> see profiles, shader clocks)
         __syncthreads();                                        // candidate list complete
-        for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X2[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < (int)C; i += TK_THREADS) atomicAdd(&X2[(cand[i] >> 24) * 32 + cslot], inc);
-        __syncthreads();
-        select_bin(X2, hist, (uint32_t)k, &misc[4], &misc[5], tid);
-        __syncthreads();
-        const uint32_t mb1 = (uint32_t)misc[4];
-        const int mabove = misc[5];
-        for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X2[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < (int)C; i += TK_THREADS) {
-          const uint32_t key = cand[i] >> 16;
-          if ((key >> 8) == mb1) atomicAdd(&X2[(key & 255u) * 32 + cslot], inc);
-        }
-        __syncthreads();
-        select_bin(X2, hist, (uint32_t)(k - mabove), &misc[6], &misc[7], tid);
-        __syncthreads();
-        const uint32_t Tm = (mb1 << 8) | (uint32_t)misc[6];
-        const int m_gt = mabove + misc[7];
-        const int m_eq_take = k - m_gt;
-        // thread t owns cand[4t .. 4t+4): list order == index order, so a block-wide exclusive scan of the
-        // per-thread (gt, eq) counts gives index-ordered output slots
-        uint32_t ck[4];
-        uint32_t cg = 0, ce = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = tid * 4 + e;
-          ck[e] = i < (int)C ? cand[i] : 0u;
-          const uint32_t key = ck[e] >> 16;
-          cg += (i < (int)C) && key > Tm;
-          ce += (i < (int)C) && key == Tm;
-        }
-        const uint32_t packed = (ce << 16) | cg;
-        const uint32_t incl = wave_incl_scan_u32(packed);
-        if (lane == 63) wcnt[wave] = incl;
-        __syncthreads();
-        uint32_t basep = 0;
-        for (int w2 = 0; w2 < wave; ++w2) basep += wcnt[w2];
-        uint32_t og = (basep & 0xffffu) + ((incl - packed) & 0xffffu);
-        uint32_t oe = (basep >> 16) + ((incl - packed) >> 16);
-        uint32_t* sel2 = X + TK_MID_C;                          // second half of X (cand uses the first 4096 words)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = tid * 4 + e;
-          if (i < (int)C) {
-            const uint32_t key = ck[e] >> 16;
-            if (key > Tm) sel2[og++] = ck[e];
-            else if (key == Tm) { if ((int)oe < m_eq_take) sel2[m_gt + oe] = ck[e]; ++oe; }
-          }
-        }
-        __syncthreads();
+        uint32_t* table = X2;                                   // [16][256]
+        uint32_t* tmp = X2 + TK_WAVES * 256;                    // [4096]
+        const int ept = ((int)C + TK_THREADS - 1) / TK_THREADS;
+        radix_pass(cand, tmp, table, hist, (int)C, ept, 0, tid);
+        radix_pass(tmp, cand, table, hist, (int)C, ept, 1, tid);
         PKV_STAMP(5);
-        rank_store(sel2, k);
+        for (int i = tid; i < k; i += TK_THREADS)
+          p.idx_out[(int64_t)vrow * p.idx_stride + i] = seg_off + (int32_t)(0xffffu - (cand[i] & 0xffffu));
       }
       PKV_STAMP(6);
       if (p.wgtrace && tid == 0) { p.wgtrace[2 * (131072 + row)] = t_start; p.wgtrace[2 * (131072 + row) + 1] = wall_clock64(); }
       return;
     }
     // too many keys at or above x* (heavy ties): full path.  Its counters must start from zero.
-    if (use_cmax) { load_all(); transform_all(); }
+    if (use_cmax) transform_all();       // the row is already in registers
     __syncthreads();
     for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
     __syncthreads();
