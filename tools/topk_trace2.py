@@ -7,7 +7,7 @@ import pyramidkv_amd as P
 from pyramidkv_amd import _native as N
 res = {}
 q, k, v = (torch.randn(1, 32, 32768, 128, device="cuda").to(torch.bfloat16) for _ in range(3))
-for kk in (17, 60, 108, 120, 143, 180, 234, 500, 2040):
+for kk in (17, 120, 234):
     buf = torch.zeros(16, dtype=torch.int64, device="cuda")
     for _ in range(3):
         P.ops.compress(q, k, v, 8, kk, "maxpool", 7)
@@ -17,5 +17,6 @@ for kk in (17, 60, 108, 120, 143, 180, 234, 500, 2040):
     N.lib.pkv_debug_topk_trace(None)
     t = buf.cpu().tolist()
     st = [t[i] - t[0] if t[i] else None for i in range(8)]
-    res[f"k{kk}"] = {"stamps_rel": st, "C": t[15], "total": t[6] - t[0]}
+    res[f"k{kk}"] = {"stamps_rel": st, "C": t[15], "total": t[6] - t[0],
+                     "finalize_rel": [t[9] - t[8], t[10] - t[8], t[11] - t[8], t[12] - t[8]]}
 print(json.dumps(res, indent=1))
