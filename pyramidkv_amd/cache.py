@@ -6,7 +6,9 @@ A decode step appends one row per head through libpkv's ``pkv_update_flatten_vie
 reference's only CUDA kernel, csrc/csrc/cuda_api.cu:11-85).  The reference subclasses transformers' ``Cache``;
 transformers 5.x made that constructor require per-layer objects (SURVEY.md section 7 hard part 6), so this class
 is a plain container with the same methods the reference's forwards call (``update``, ``get_seq_length``,
-``__len__``, ``__getitem__``, ``to_legacy_cache``, ``from_legacy_cache``).  No nvtx ranges (reference :63-69).
+``__len__``, ``__getitem__``, ``to_legacy_cache``, ``from_legacy_cache``) plus the three the transformers-5 model
+forward asks every cache for (``is_sliding``, ``get_query_offset``, ``get_mask_sizes``).  No nvtx ranges
+(reference :63-69).
 """
 from __future__ import annotations
 
@@ -18,10 +20,14 @@ from . import ops
 
 
 class DynamicCacheSplitHeadFlatten:
+    # the flat append; tests on CPU swap in the oracle's restatement (the product path is the HIP kernel only)
+    _append = staticmethod(ops.update_flatten_view)
+    is_sliding = [False]          # transformers 5 masking_utils: no sliding-window layers in this cache
+
     def __init__(self) -> None:
         self.key_cache: List[torch.Tensor] = []
         self.value_cache: List[torch.Tensor] = []
-        self._seen_tokens = 0
+        self._seen_tokens = 0     # tokens of the sequence so far; the patched forward sets it (reference llama_model.py:2386)
 
     def __len__(self):
         return len(self.key_cache)
@@ -45,16 +51,24 @@ class DynamicCacheSplitHeadFlatten:
             assert bs == 1 and seqlen == 1
             head_lens = cache_kwargs["head_lens"]
             cu_klen = cache_kwargs["cu_klen"]
-            self.key_cache[layer_idx] = ops.update_flatten_view(self.key_cache[layer_idx].view(-1, dim),
-                                                                key_states.view(-1, dim), head_lens, cu_klen)
-            self.value_cache[layer_idx] = ops.update_flatten_view(self.value_cache[layer_idx].view(-1, dim),
-                                                                  value_states.view(-1, dim), head_lens, cu_klen)
+            self.key_cache[layer_idx] = self._append(self.key_cache[layer_idx].view(-1, dim),
+                                                     key_states.view(-1, dim), head_lens, cu_klen)
+            self.value_cache[layer_idx] = self._append(self.value_cache[layer_idx].view(-1, dim),
+                                                       value_states.view(-1, dim), head_lens, cu_klen)
         return self.key_cache[layer_idx], self.value_cache[layer_idx]
 
     def get_seq_length(self, layer_idx: Optional[int] = 0) -> int:
         if len(self.key_cache) <= layer_idx:
             return 0
-        return 1                                                                 # "has content", as the reference (:80-81)
+        # the reference returns 1 = "has content" (:80-81); once a forward keeps _seen_tokens (reference
+        # llama_model.py:2386) the true sequence length is reported, which is what transformers 5 derives positions from
+        return self._seen_tokens if self._seen_tokens > 0 else 1
+
+    def get_query_offset(self, layer_idx: int = 0) -> int:
+        return self._seen_tokens if len(self.key_cache) > layer_idx else 0
+
+    def get_mask_sizes(self, query_length: int, layer_idx: int = 0):
+        return self.get_query_offset(layer_idx) + query_length, 0
 
     def get_max_length(self) -> Optional[int]:
         return None

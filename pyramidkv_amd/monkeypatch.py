@@ -12,8 +12,12 @@ contract of ``llama_model.py:157-172`` on top of the transformers-5 attention mo
     cache at decode.
 
 As in the reference the cache stores all H (query) heads, because K/V are expanded before ``update_kv``.
-``adakv`` / ``headkv`` need the var-len flash-attention decode path of the reference (flash_attn_varlen_func)
-and are not wired here; ``pyramidkv``, ``snapkv``, ``h2o``, ``streamingllm`` are.
+``pyramidkv``, ``snapkv``, ``h2o``, ``streamingllm`` use the model's own cache object.  ``adakv`` / ``headkv``
+(reference llama_model.py:2236-2391 / :2393-2540) keep a FLAT per-head var-len cache: pass a
+``pyramidkv_amd.DynamicCacheSplitHeadFlatten()`` as ``past_key_values`` (batch 1, as the reference); the decode step
+appends through ``pkv_update_flatten_view`` and attends per head over its own rows - the reference calls
+``flash_attn_varlen_func`` there, this adapter uses a padded-batch softmax written in plain PyTorch ops (caller-side
+glue, like the rest of this file).
 """
 from __future__ import annotations
 
@@ -31,6 +35,7 @@ _METHODS: Dict[str, tuple] = {
     "h2o": ("init_H2O", False),
     "streamingllm": ("init_StreamingLLM", False),
 }
+_FLAT_METHODS: Dict[str, str] = {"adakv": "init_adakv", "headkv": "init_headkv"}
 # the module whose init_* functions build the clusters; tests swap in an oracle-backed stand-in on CPU
 _cluster_module = _utils
 # hand K/V to update_kv BEFORE repeat_kv when the cluster accepts it (pyramidkv_amd's do); False = the reference's order
@@ -109,15 +114,80 @@ def _make_forward(method: str, apply_rotary_pos_emb: Callable):
     return forward
 
 
+def varlen_decode_attention(q, k_flat, v_flat, cu_klen, max_seqlen_k, scaling):
+    """One query token per head over a flat var-len cache: q [H, D], k_flat/v_flat [sum_h len_h, D], head h owns rows
+    cu_klen[h]..cu_klen[h+1].  What flash_attn_varlen_func(..., cu_seqlens_q=arange(H+1), cu_seqlens_k=cu_klen,
+    max_seqlen_q=1, causal=True) computes in the reference (llama_model.py:2377-2383): fp32 softmax per head."""
+    H, D = q.shape
+    cu = cu_klen.to(torch.long)
+    lens = cu[1:] - cu[:-1]
+    j = torch.arange(int(max_seqlen_k), device=q.device)
+    valid = j[None, :] < lens[:, None]                                      # [H, max]
+    rows = torch.where(valid, cu[:-1, None] + j[None, :], torch.zeros((), dtype=torch.long, device=q.device))
+    kp = k_flat[rows]                                                       # [H, max, D]
+    vp = v_flat[rows]
+    s = torch.einsum("hd,hjd->hj", q.float(), kp.float()) * scaling
+    s = s.masked_fill(~valid, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("hj,hjd->hd", p, vp.float()).to(q.dtype)
+
+
+def _make_flat_forward(method: str, apply_rotary_pos_emb: Callable):
+    init_name = _FLAT_METHODS[method]
+
+    def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+        input_shape = hidden_states.shape[:-1]
+        hidden_shape = (*input_shape, -1, self.head_dim)
+        q = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        k = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        v = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        cos, sin = position_embeddings
+        q, k = apply_rotary_pos_emb(q, k, cos, sin)
+        k = _repeat_kv(k, self.num_key_value_groups)                      # llama_model.py:2285-2286
+        v = _repeat_kv(v, self.num_key_value_groups)
+        q_len = q.shape[-2]
+        flat = past_key_values is not None and hasattr(past_key_values, "key_cache")
+        if past_key_values is not None and not flat:
+            raise TypeError(f"{method} keeps a flat per-head cache: pass past_key_values=pyramidkv_amd.DynamicCacheSplitHeadFlatten()")
+        if not flat or len(past_key_values.key_cache) <= self.layer_idx:  # prefill (reference :2300-2360)
+            if flat:
+                assert q.shape[0] == 1, "flat var-len cache: batch 1 (reference pyramidkv_utils.py:724)"
+                getattr(_cluster_module, init_name)(self)                 # built once per module (:1049, :1076)
+                kf, vf = self.kv_cluster.update_kv(k, q, v)               # :2310
+                past_key_values.update(kf, vf, self.layer_idx)
+                if self.layer_idx == 0:
+                    past_key_values._seen_tokens += q_len                 # :2386
+            attn = _attend(self, q, k, v, attention_mask, True)           # the prompt attends to the full K/V
+        else:                                                             # decode (reference :2362-2384)
+            assert q.shape[0] == 1 and q_len == 1
+            cl = self.kv_cluster
+            kf, vf = past_key_values.update(k, v, self.layer_idx, {"head_lens": cl.head_lens, "cu_klen": cl.cu_klen})
+            cl.klen_sum += q.shape[1]
+            cl.max_seqlen_k += 1
+            cl.cu_klen += cl.cu_offset
+            cl.head_lens += 1
+            if self.layer_idx == 0:
+                past_key_values._seen_tokens += 1
+            out = varlen_decode_attention(q[0, :, 0], kf, vf, cl.cu_klen, cl.max_seqlen_k, self.scaling)   # [H, D]
+            attn = out[None, None]                                        # [1, 1, H, D]
+        attn = attn.reshape(*input_shape, -1).contiguous()
+        return self.o_proj(attn), None
+
+    forward.__name__ = f"attn_forward_{method}"
+    return forward
+
+
 def _replace(module_path: str, class_name: str, method: str):
-    if method not in _METHODS:
-        raise ValueError(f"method {method!r} is not wired in pyramidkv_amd.monkeypatch (supported: {sorted(_METHODS)})")
+    if method not in _METHODS and method not in _FLAT_METHODS:
+        raise ValueError(f"method {method!r} is not wired in pyramidkv_amd.monkeypatch "
+                         f"(supported: {sorted(list(_METHODS) + list(_FLAT_METHODS))})")
     import importlib
     mod = importlib.import_module(module_path)
     cls = getattr(mod, class_name)
     if not hasattr(cls, "_pkv_original_forward"):
         cls._pkv_original_forward = cls.forward
-    cls.forward = _make_forward(method, mod.apply_rotary_pos_emb)
+    make = _make_flat_forward if method in _FLAT_METHODS else _make_forward
+    cls.forward = make(method, mod.apply_rotary_pos_emb)
 
 
 def replace_llama(method, model_name=None):

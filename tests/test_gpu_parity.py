@@ -700,6 +700,59 @@ def test_compress_long_sequence_selection_properties(P):
     assert torch.equal(kc, ref_k) and torch.equal(vc, ref_v)
 
 
+@pytest.mark.parametrize("method", ["adakv", "headkv"])
+def test_replace_llama_flat_cache_methods_on_gpu(P, method):
+    """replace_llama('adakv'|'headkv') with the real HIP clusters and the HIP flat append on a tiny bf16 Llama."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from pyramidkv_amd import monkeypatch as mp
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=97, hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=128, max_position_embeddings=8192)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(DEV).eval()
+    S, cap, w, new, H = 1024, 64, 8, 3, 4
+    ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(1)).to(DEV)
+    with torch.no_grad():
+        base = model(ids).logits
+    try:
+        mp.replace_llama(method)
+        for layer in model.model.layers:
+            c = layer.self_attn.config
+            c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = w, cap, 7, "maxpool", None
+            c.floor, c.normalize = 0.2, True
+            c.head_capacity = torch.tensor([[30, 70, 56, 68]] * 2, dtype=torch.int32)
+        cache = P.DynamicCacheSplitHeadFlatten()
+        with torch.no_grad():
+            out = model(ids, past_key_values=cache, use_cache=True)
+        assert torch.allclose(out.logits.float(), base.float(), atol=2e-2, rtol=2e-2)
+        cls = [l.self_attn.kv_cluster for l in model.model.layers]
+        assert isinstance(cls[0], P.AdaKVCluster if method == "adakv" else P.HeadKVCluster)
+        want = [int(c.klen_sum) for c in cls]
+        if method == "headkv":
+            assert want == [30 + 70 + 56 + 68 + H * w] * 2
+        assert [cache.key_cache[i].shape[0] for i in range(2)] == want
+        k0 = cache.key_cache[0].clone()
+        lens0, cu0 = cls[0].head_lens.clone(), cls[0].cu_klen.clone()
+        nxt = out.logits[:, -1:].argmax(-1)
+        with torch.no_grad():
+            for t in range(new):
+                o = model(nxt, past_key_values=cache, use_cache=True)
+                nxt = o.logits[:, -1:].argmax(-1)
+                assert torch.isfinite(o.logits.float()).all()
+        assert cache.get_seq_length() == S + new
+        assert [cache.key_cache[i].shape[0] for i in range(2)] == [x + H * new for x in want]
+        k1, cu1 = cache.key_cache[0], cls[0].cu_klen
+        for h in range(H):      # every head kept its compacted prompt rows in place, the new rows follow them
+            a0, n0, a1 = int(cu0[h]), int(lens0[h]), int(cu1[h])
+            assert torch.equal(k1[a1:a1 + n0], k0[a0:a0 + n0])
+            assert int(cu1[h + 1]) - a1 == n0 + new
+    finally:
+        mp.restore()
+        for layer in model.model.layers:
+            if hasattr(layer.self_attn, "kv_cluster"):
+                del layer.self_attn.kv_cluster
+
+
 # ----------------------------------------------------------------------------------------- full-size checks
 @pytest.mark.parametrize("B,cap", [(2, 128), (1, 2048), (2, 4096)])
 def test_full_size_selection_properties(P, B, cap):

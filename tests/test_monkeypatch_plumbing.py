@@ -138,7 +138,7 @@ def test_passthrough_equals_unpatched_generation(patched):
 
 def test_unknown_method_raises(patched):
     with pytest.raises(ValueError):
-        patched.replace_llama("adakv")
+        patched.replace_llama("cam")
 
 
 @pytest.mark.parametrize("method", ["pyramidkv", "snapkv"])
@@ -188,3 +188,98 @@ def test_unexpanded_kv_branch_gives_the_same_cache(patched, method):
     assert torch.allclose(a[0], b[0], atol=1e-5, rtol=1e-5)
     for (ka, va), (kb, vb) in zip(a[1], b[1]):
         assert torch.equal(ka, kb) and torch.equal(va, vb)
+
+
+# ------------------------------------------------------------------------------------------ adakv / headkv (flat cache)
+class _OracleFlatCluster:
+    """Stand-in for AdaKVCluster / HeadKVCluster on CPU: oracle update_kv + the metadata attributes the forward bumps."""
+
+    def __init__(self, kind, cfg, layer_idx):
+        self.kind, self.cfg, self.layer_idx = kind, cfg, layer_idx
+
+    def update_kv(self, k, q, v):
+        c = self.cfg
+        if self.kind == "adakv":
+            kf, vf, m = O.adakv_update_kv(k, q, v, c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling,
+                                          c.floor, c.normalize)
+        else:
+            kf, vf, m = O.headkv_update_kv(k, q, v, c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling,
+                                           c.head_capacity, self.layer_idx)
+        self.head_lens, self.cu_klen, self.cu_qlen, self.cu_offset = m.head_lens, m.cu_klen, m.cu_qlen, m.cu_offset
+        self.max_seqlen_k, self.klen_sum = m.max_seqlen_k, m.klen_sum
+        return kf, vf
+
+
+def _flat_module():
+    m = types.SimpleNamespace()
+
+    def init(kind):
+        def f(self):
+            if not hasattr(self, "kv_cluster"):
+                self.kv_cluster = _OracleFlatCluster(kind, self.config, self.layer_idx)
+        return f
+    m.init_adakv, m.init_headkv = init("adakv"), init("headkv")
+    return m
+
+
+def test_varlen_decode_attention_matches_per_head_loop():
+    from pyramidkv_amd.monkeypatch import varlen_decode_attention
+    g = torch.Generator().manual_seed(0)
+    lens = [5, 1, 17, 9]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    q = torch.randn(4, 16, generator=g)
+    kf, vf = torch.randn(sum(lens), 16, generator=g), torch.randn(sum(lens), 16, generator=g)
+    got = varlen_decode_attention(q, kf, vf, cu, max(lens), 0.25)
+    for h, n in enumerate(lens):
+        a, b = int(cu[h]), int(cu[h + 1])
+        p = torch.softmax((kf[a:b] @ q[h]) * 0.25, 0)
+        assert torch.allclose(got[h], p @ vf[a:b], atol=1e-6)
+
+
+@pytest.mark.parametrize("method", ["adakv", "headkv"])
+def test_flat_cache_methods_generate(patched, method):
+    """replace_llama('adakv'|'headkv') with a DynamicCacheSplitHeadFlatten: prompt logits untouched, per-layer flat
+    lengths = sum_h(cap_h + w), decode appends one row per head and keeps positions running."""
+    import pyramidkv_amd as P
+    model = _tiny("llama")
+    S, new, cap, w = 200, 5, 64, 8
+    ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        base = model(ids).logits
+    patched._cluster_module = _flat_module()
+    patched.replace_llama(method)
+    H, Lyr = model.config.num_attention_heads, model.config.num_hidden_layers
+    for layer in model.model.layers:
+        c = layer.self_attn.config
+        c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = w, cap, 7, "maxpool", None
+        c.floor, c.normalize = 0.2, True
+        c.head_capacity = torch.tensor([[40, 72]] * Lyr, dtype=torch.int32)           # HeadKV: per (layer, head) budgets
+    saved = P.DynamicCacheSplitHeadFlatten._append
+    P.DynamicCacheSplitHeadFlatten._append = staticmethod(O.update_flatten_view)     # CPU: the oracle's flat append
+    try:
+        cache = P.DynamicCacheSplitHeadFlatten()
+        with torch.no_grad():
+            out = model(ids, past_key_values=cache, use_cache=True)
+        assert torch.allclose(out.logits, base, atol=1e-4, rtol=1e-4)
+        assert cache.get_seq_length() == S and len(cache) == Lyr
+        want = [int(l.self_attn.kv_cluster.klen_sum) for l in model.model.layers]   # sum_h (cap_h + w), per layer
+        if method == "headkv":
+            assert want == [(40 + 72) + H * w] * Lyr
+        else:       # budgets are rounded per head (:719): the total may be off the nominal H * cap by a token or two
+            assert all(abs(x - H * cap) <= H for x in want)
+        assert [cache.key_cache[i].shape[0] for i in range(Lyr)] == want
+        nxt = out.logits[:, -1:].argmax(-1)
+        with torch.no_grad():
+            for t in range(new):
+                o = model(nxt, past_key_values=cache, use_cache=True)               # positions come from the cache
+                nxt = o.logits[:, -1:].argmax(-1)
+                assert torch.isfinite(o.logits).all()
+        assert cache.get_seq_length() == S + new
+        assert [cache.key_cache[i].shape[0] for i in range(Lyr)] == [x + H * new for x in want]
+        cl = model.model.layers[0].self_attn.kv_cluster
+        assert int(cl.klen_sum) == want[0] + H * new and int(cl.cu_klen[-1]) == want[0] + H * new
+    finally:
+        P.DynamicCacheSplitHeadFlatten._append = saved
+        for layer in model.model.layers:
+            if hasattr(layer.self_attn, "kv_cluster"):
+                del layer.self_attn.kv_cluster

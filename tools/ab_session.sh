@@ -5,9 +5,5 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 600 python tools/topk_trace2.py > $O/topk_trace2.json 2> $O/topk_trace2.err
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/topk_trace2.json'))
-for k,v in d.items(): print(k, v)
-PY
+timeout 900 python -m pytest tests -m gpu -q --timeout 600 > $O/pytest.txt 2>&1
+tail -12 $O/pytest.txt
