@@ -140,7 +140,9 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     }
     const int sph = (d->S + 127) / 128;                                     // stages per head group
     const int64_t total = (int64_t)d->B * (d->H / d->kv_group) * sph;
-    const int target = logits_v2_wgs() > 0 ? logits_v2_wgs() : 8 * cus;     // two resident generations of workgroups (measured best of 3..16 per CU, all within 3 %)
+    // workgroups: 8 per CU for C = 8 (measured best of 3..16, all within 3 %); 4 per CU when a stage carries more columns
+    // (un-expanded GQA K: 2048 single-stage workgroups cost 2.5 us more than 256..1024 with 2..8 stages each)
+    const int target = logits_v2_wgs() > 0 ? logits_v2_wgs() : (C > 8 ? 4 : 8) * cus;
     int nst = (int)((total + target - 1) / target);
     nst = std::max(1, std::min(nst, std::min(sph, 64)));
     lp.nst = nst;

@@ -5,5 +5,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests -m gpu -q --timeout 600 > $O/pytest.txt 2>&1
-tail -12 $O/pytest.txt
+for w in 256 512 768 1024 2048; do
+PKV_LOGITS_V2_WGS=$w timeout 600 python tools/dedup_breakdown.py > $O/dedup_w$w.json 2>> $O/dedup.err
+python - <<PY
+import json
+d=json.load(open("gpurun_out/dedup_w$w.json")); print("wgs $w", d["k120"])
+PY
+done
