@@ -108,13 +108,20 @@ def main():
         sets.append((q, k, v))
 
     def one_step():
-        outs = None
+        # the one exchange step of the path (indices, KBs) is issued asynchronously: layer i+1's update_kv does not
+        # depend on layer i's gathered indices, so the latency-bound collective overlaps with it; at most two are
+        # in flight and all are waited for (on the stream) before the step ends
+        outs, pending = None, []
         for layer in range(NUM_LAYERS):
             q, k, v = sets[layer % NSETS]
             kc, vc, idx = P.ops.compress(q, k, v, w, ks[layer], "maxpool", 7, return_indices=True)
             if world > 1:
-                idx = pdist.allgather_indices(idx)
+                pending.append(pdist.allgather_indices_async(idx))
+                if len(pending) > 2:
+                    idx = pending.pop(0).wait()
             outs = (kc, vc, idx)
+        for h in pending:
+            outs = (outs[0], outs[1], h.wait())
         return outs
 
     def barrier():

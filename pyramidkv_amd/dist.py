@@ -36,6 +36,34 @@ def allgather_indices(idx_local: torch.Tensor, group: Optional[dist.ProcessGroup
     return out.view(world, B, Hl, k).permute(1, 0, 2, 3).reshape(B, world * Hl, k)
 
 
+class PendingIndices:
+    """Handle of an all-gather in flight (``allgather_indices_async``): ``wait()`` makes the CURRENT stream wait for it
+    (no host block with the nccl/RCCL backend) and returns the [B, H, k] tensor."""
+
+    def __init__(self, out, work, shape):
+        self._out, self._work, self._shape = out, work, shape
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        world, B, Hl, k = self._shape
+        return self._out.view(world, B, Hl, k).permute(1, 0, 2, 3).reshape(B, world * Hl, k)
+
+
+def allgather_indices_async(idx_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> PendingIndices:
+    """Same exchange as ``allgather_indices`` but not waited for: the next layer's update_kv does not depend on this
+    layer's gathered indices, so the KB-sized, latency-bound collective overlaps with it (RCCL runs it on its own
+    stream).  Call ``.wait()`` before the indices are consumed."""
+    world = dist.get_world_size(group)
+    B, Hl, k = idx_local.shape
+    if world == 1:
+        return PendingIndices(idx_local.contiguous(), None, (1, B, Hl, k))
+    out = torch.empty(world * B, Hl, k, dtype=idx_local.dtype, device=idx_local.device)
+    work = dist.all_gather_into_tensor(out, idx_local.contiguous(), group=group, async_op=True)
+    return PendingIndices(out, work, (world, B, Hl, k))
+
+
 class HeadShardedCluster:
     """Wraps a SnapKV/PyramidKV/H2O-style cluster: ``update_kv`` runs the local heads through the HIP
     path and all-gathers the selected indices.  ``select_fn(q,k,v) -> (kc, vc, idx)`` is the local

@@ -38,6 +38,11 @@ def _worker(rank, world, port, ret):
     kc, vc, idx_all = cl.update_kv(k[:, h0:h1], q[:, h0:h1], v[:, h0:h1])
     kr, vr, ridx = O.snapkv_update_kv(k, q, v, w, cap, 7, "maxpool", return_indices=True)
     ok = torch.equal(idx_all.long(), ridx) and torch.equal(kc, kr[:, h0:h1]) and torch.equal(vc, vr[:, h0:h1])
+    # the asynchronous form used by bench.py (several gathers in flight, waited for later) gives the same tensor
+    _, _, idx_loc = select(q[:, h0:h1], k[:, h0:h1], v[:, h0:h1])
+    handles = [pdist.allgather_indices_async(idx_loc), pdist.allgather_indices_async(idx_loc + 1)]
+    ok = ok and torch.equal(handles[0].wait().long(), ridx) and torch.equal(handles[1].wait().long(), ridx + 1)
+    ok = ok and torch.equal(handles[0].wait().long(), ridx)            # wait() is idempotent
     ret[rank] = bool(ok) and idx_all.shape == (B, H, cap - w)
     dist.barrier()
     dist.destroy_process_group()

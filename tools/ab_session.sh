@@ -5,10 +5,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-for w in 256 512 768 1024 2048; do
-PKV_LOGITS_V2_WGS=$w timeout 600 python tools/dedup_breakdown.py > $O/dedup_w$w.json 2>> $O/dedup.err
-python - <<PY
-import json
-d=json.load(open("gpurun_out/dedup_w$w.json")); print("wgs $w", d["k120"])
-PY
-done
+PKV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_n2_gloo.json 2> $O/bench_n2_gloo.err
+tail -1 $O/bench_n2_gloo.json | cut -c1-500; tail -3 $O/bench_n2_gloo.err
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | cut -c1-200
