@@ -1,10 +1,13 @@
 #!/bin/bash
+# Short GPU session for A/B work: parity suite + one bench line (edit freely; tools/gpu_session.sh is the full one).
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-PKV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_n2_gloo.json 2> $O/bench_n2_gloo.err
-tail -1 $O/bench_n2_gloo.json | cut -c1-500; tail -3 $O/bench_n2_gloo.err
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | cut -c1-200
+timeout 900 python -m pytest tests -m gpu -q --timeout 600 > $O/pytest.txt 2>&1
+tail -3 $O/pytest.txt
+timeout 600 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(d['value'], d['kv_compress_ms_per_layer'], {k:v['avg_us'] for k,v in d['roofline_kernels'].items()}, d.get('extras',{}).get('gqa_dedup_us_per_layer'))"
