@@ -10,6 +10,7 @@
 #include <mutex>
 #include <vector>
 
+namespace pkv { thread_local KernelEvents* g_kev = nullptr; }
 using namespace pkv;
 
 namespace {
@@ -53,19 +54,25 @@ hipEvent_t get_event() {
   return e;
 }
 
+// ext = the scope holds exactly one kernel launched through PKV_KLAUNCH: its events ride on the dispatch (kernel begin /
+// end).  Otherwise (several launches per scope) a pair of hipEventRecords brackets the scope.
 struct ProfScope {
-  bool on; int id; hipStream_t st; hipEvent_t a, b;
-  ProfScope(int id_, hipStream_t st_) : on(g_prof_on), id(id_), st(st_) {
+  bool on, ext; int id; hipStream_t st; hipEvent_t a, b; KernelEvents kev;
+  ProfScope(int id_, hipStream_t st_, bool ext_ = false) : on(g_prof_on), ext(ext_), id(id_), st(st_) {
     if (on) {
       { std::lock_guard<std::mutex> lk(g_prof_mu); a = get_event(); b = get_event(); }
-      (void)hipEventRecord(a, st);
+      if (ext) { kev = {a, b, false}; g_kev = &kev; }
+      else (void)hipEventRecord(a, st);
     }
   }
   ~ProfScope() {
     if (on) {
-      (void)hipEventRecord(b, st);
+      bool ok = true;
+      if (ext) { g_kev = nullptr; ok = kev.used; }
+      else (void)hipEventRecord(b, st);
       std::lock_guard<std::mutex> lk(g_prof_mu);
-      g_pending.push_back({id, a, b});
+      if (ok) g_pending.push_back({id, a, b});
+      else { g_free_events.push_back(a); g_free_events.push_back(b); }
     }
   }
 };
@@ -148,11 +155,11 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     lp.nst = nst;
     lp.nT = nT_used = (sph + nst - 1) / nst;
     lp.nt = logits_v2_nt();
-    ProfScope ps(PKV_K_LOGITS, st);
+    ProfScope ps(PKV_K_LOGITS, st, true);
     hipError_t e = launch_logits2(d->dtype, lp, st);
     if (e != hipSuccess) return hip_fail(e);
   } else {
-    ProfScope ps(PKV_K_LOGITS, st);
+    ProfScope ps(PKV_K_LOGITS, st, true);
     hipError_t e = launch_logits(d->dtype, lp, st);
     if (e != hipSuccess) return hip_fail(e);
   }
@@ -167,7 +174,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   fp.trace = g_topk_trace ? g_topk_trace + 8 : nullptr;
   fp.wgtrace = g_wg_trace; fp.nt = finalize_nt();
   {
-    ProfScope ps(PKV_K_FINALIZE, st);
+    ProfScope ps(PKV_K_FINALIZE, st, true);
     hipError_t e = launch_finalize(d->dtype, fp, st);
     if (e != hipSuccess) return hip_fail(e);
   }
@@ -228,7 +235,7 @@ int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t strid
     if (lds > 160 * 1024 || 16 * (size_t)tp.Lw > 65536) return PKV_ERR_UNSUPPORTED;
     const size_t xw = (size_t)(tp.kpad > 8192 ? tp.kpad : 8192);
     tp.dual = lds >= (size_t)2 * 16 * tp.Lw + 4 * xw + 4 * 256 + 4 * 64 + 4 * 8192 ? 1 : 0;
-    ProfScope ps(PKV_K_TOPK, st);
+    ProfScope ps(PKV_K_TOPK, st, true);
     hipError_t e = launch_topk(dtype, nrows, tp, lds, st);
     return e == hipSuccess ? PKV_OK : hip_fail(e);
   };
@@ -267,7 +274,7 @@ GatherParams make_gather(const pkv_desc* d, const void* k, const void* v, void* 
 }
 
 int do_gather(const GatherParams& g, int max_rows, hipStream_t st) {
-  ProfScope ps(PKV_K_GATHER, st);
+  ProfScope ps(PKV_K_GATHER, st, true);
   hipError_t e = launch_gather(g, max_rows, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }

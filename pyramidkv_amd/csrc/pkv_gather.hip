@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
 
 hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st) {
   dim3 grid((max_rows + GA_ROWS - 1) / GA_ROWS, p.B * p.H);
-  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, st, p);
+  PKV_KLAUNCH(gather_kernel, grid, dim3(256), 0, st, p);
   return hipGetLastError();
 }
 

@@ -1,9 +1,25 @@
 // pkv_kernels.hpp — kernel parameter blocks and launch prototypes (internal to libpkv).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace pkv {
+
+// Per-kernel timing (pkv_prof_*): while a single-kernel profiling scope is open the API layer points g_kev at a pair of
+// events and the launcher attaches them to the dispatch itself (hipExtLaunchKernelGGL): they carry the kernel's own begin
+// and end timestamps, the same interval rocprofv3 reports, with no extra barrier packets in the stream.
+struct KernelEvents { hipEvent_t start, stop; bool used; };
+extern thread_local KernelEvents* g_kev;
+#define PKV_KLAUNCH(kernel, grid, block, lds, st, ...)                                                              \
+  do {                                                                                                              \
+    if (pkv::g_kev) {                                                                                               \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, pkv::g_kev->start, pkv::g_kev->stop, 0, __VA_ARGS__);     \
+      pkv::g_kev->used = true;                                                                                      \
+    } else {                                                                                                        \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                                \
+    }                                                                                                               \
+  } while (0)
 
 struct LogitsParams {
   unsigned long long* wgtrace;   // debug: per-workgroup (start,end) wall clock, may be null

@@ -559,7 +559,7 @@ hipError_t launch_logits2(int dtype, const LogitsParams& p, hipStream_t st) {
   const int nct = (C + 15) / 16;
   dim3 grid(p.nT, p.B * (p.H / p.G));
   const size_t lds = logits2_lds_bytes(C);
-#define PKV_L2(TT, NCT, NTL) hipLaunchKernelGGL((logits2_kernel<TT, NCT, NTL>), grid, dim3(256), lds, st, p)
+#define PKV_L2(TT, NCT, NTL) PKV_KLAUNCH((logits2_kernel<TT, NCT, NTL>), grid, dim3(256), lds, st, p)
   if (dtype == 0) {
     if (nct == 1) { if (p.nt) PKV_L2(BF16, 1, true); else PKV_L2(BF16, 1, false); }
     else          { if (p.nt) PKV_L2(BF16, 2, true); else PKV_L2(BF16, 2, false); }
@@ -583,7 +583,7 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
       if (e_ != hipSuccess) return e_;                                                                                \
     }                                                                                                                  \
-    hipLaunchKernelGGL((logits_kernel<TT, KPW, NT>), grid, dim3(256), lds, st, p);                                    \
+    PKV_KLAUNCH((logits_kernel<TT, KPW, NT>), grid, dim3(256), lds, st, p);                                           \
   } while (0)
   if (dtype == 0) {
     if (tile == 128) { if (p.nt) PKV_LAUNCH(BF16, 32, true); else PKV_LAUNCH(BF16, 32, false); }
@@ -599,8 +599,8 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st) {
   const int L = p.S - p.w;
   dim3 grid((L + FN_OUT - 1) / FN_OUT, p.B * p.H);
-  if (dtype == 0) hipLaunchKernelGGL(finalize_kernel<BF16>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(finalize_kernel<F16>, grid, dim3(256), 0, st, p);
+  if (dtype == 0) PKV_KLAUNCH(finalize_kernel<BF16>, grid, dim3(256), 0, st, p);
+  else PKV_KLAUNCH(finalize_kernel<F16>, grid, dim3(256), 0, st, p);
   return hipGetLastError();
 }
 

@@ -663,7 +663,7 @@ hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hip
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(fn, dim3(rows), dim3(TK_THREADS), lds, st, p);
+  PKV_KLAUNCH(fn, dim3(rows), dim3(TK_THREADS), lds, st, p);
   return hipGetLastError();
 }
 
