@@ -686,6 +686,35 @@ def test_topk_long_rows_vs_oracle(P, L, k):
     assert torch.equal(got, want)
 
 
+def test_topk_randomised_shapes_vs_oracle(P):
+    """80 seeded random (rows, L, k, tie structure, dtype) cases across every code path of the selection (prefilter /
+    direct rank / radix-ordered candidates / full select / bitonic / segmented long rows), incl. L = 1, k = L, k = 1 and
+    lengths around the 8-key chunk, 512-key wave and 32k segment boundaries: indices bit-identical to the oracle."""
+    rng = np.random.default_rng(2024)
+    edge_L = [1, 2, 7, 8, 9, 15, 16, 17, 511, 512, 513, 1023, 1025, 8191, 8193, 32759, 32768, 32769, 57344, 57345, 65535, 65537, 98305]
+    for case in range(80):
+        L = int(edge_L[case]) if case < len(edge_L) else int(rng.integers(1, 140000))
+        kmax = min(L, 16384 if L <= 32768 else 4096)       # long rows: nseg * k <= 57344 and k <= 4096 keep the merge stage in LDS
+        k = int(rng.choice([1, min(17, kmax), min(120, kmax), kmax, int(rng.integers(1, kmax + 1))]))
+        rows = int(rng.integers(1, 4))
+        dt = torch.bfloat16 if case % 3 else torch.float16
+        g = torch.Generator().manual_seed(1000 + case)
+        kind = case % 4
+        if kind == 0:
+            s = torch.randn(rows, L, generator=g)
+        elif kind == 1:
+            s = (torch.rand(rows, L, generator=g) * 5).floor() / 8                     # 5 distinct values
+        elif kind == 2:
+            s = torch.full((rows, L), 0.25)                                             # one plateau
+            s[:, :: max(1, L // 7)] = 1.0
+        else:
+            s = torch.softmax(torch.randn(rows, L, generator=g) * 3, -1)               # heavy tail like real scores
+        s = s.to(dt)
+        got = P.ops.topk(s.to(DEV), k).cpu().long()
+        want = O.topk_canonical(s, k)
+        assert torch.equal(got, want), (case, rows, L, k, str(dt), kind)
+
+
 def test_compress_long_sequence_selection_properties(P):
     """S = 131072 (L > one top-k workgroup): update_kv end to end, checked by size-independent properties."""
     B, H, S, w, kk = 1, 2, 131072, 8, 120

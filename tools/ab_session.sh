@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests -m gpu -q --timeout 600 > $O/pytest.txt 2>&1
+timeout 900 python -m pytest tests -m gpu -q --timeout 600 -x > $O/pytest.txt 2>&1
 tail -3 $O/pytest.txt
 timeout 600 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys
