@@ -300,6 +300,51 @@ def test_compress_self_consistent_and_match_rate(P, dt, S, cap):
     assert same_set >= 0.5
 
 
+def test_compress_randomised_configs(P):
+    """40 seeded random update_kv configurations - batch, heads, GQA group (K/V handed over un-expanded), ragged S, window,
+    pooling kind / width, k, dtype, transposed (strided) K/V views: scores within the 1-ulp bar of the oracle, indices ==
+    canonical top-k of the kernel's own scores, K/V == exact gather of those rows + the window tail."""
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for case in range(40):
+        B = int(rng.integers(1, 3))
+        g = int(rng.choice([1, 1, 2, 4]))
+        Hk = int(rng.integers(1, 4))
+        H = Hk * g
+        w = int(rng.choice([1, 4, 8, 8, 16, 32])) if g * 32 <= 256 else 8
+        if g * w > 256:
+            w = 8
+        S = int(rng.integers(w + 40, 5000))
+        pool = str(rng.choice(["maxpool", "avgpool"]))
+        ks = int(rng.choice([1, 3, 5, 7, 9]))
+        kk = int(rng.integers(1, min(S - w, 600) + 1))
+        dt = "bf16" if case % 2 else "fp16"
+        q, k_full, v_full = make_qkv(B, H, S, 128, dt, "gauss", 500 + case)
+        k_un, v_un = k_full[:, ::g].contiguous(), v_full[:, ::g].contiguous()          # [B, Hk, S, D]
+        # what repeat_kv hands over; materialised: with ONE kv head the reshape stays a stride-0 view and ATen's CPU
+        # fp16 matmul then takes another kernel whose results differ in the last bit from the contiguous case
+        k_exp = k_un[:, :, None].expand(B, Hk, g, S, 128).reshape(B, H, S, 128).contiguous()
+        v_exp = v_un[:, :, None].expand(B, Hk, g, S, 128).reshape(B, H, S, 128).contiguous()
+        qd = q.to(DEV)
+        if case % 3 == 0:      # transposed views: [B, S, Hk, D] storage, as the attention projection produces them
+            kd = k_un.to(DEV).transpose(1, 2).contiguous().transpose(1, 2)
+            vd = v_un.to(DEV).transpose(1, 2).contiguous().transpose(1, 2)
+        else:
+            kd, vd = k_un.to(DEV), v_un.to(DEV)
+        kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk, pool, ks, kv_group=g, return_indices=True)
+        sg = P.ops.score_window(qd, kd, w, pool, ks, kv_group=g)
+        so = O.pool_scores(O.window_scores(q, k_exp, w), pool, ks)
+        mism = float(np.mean(bits(sg.cpu()) != bits(so)))
+        worst = max(worst, mism)
+        assert mism <= SCORE_MISMATCH_FRAC, (case, mism)
+        assert int(np.abs(ord16(sg.cpu()).astype(np.int64) - ord16(so).astype(np.int64)).max()) <= 1, case
+        want = O.topk_canonical(sg.cpu(), kk)
+        assert torch.equal(idx.cpu().long(), want), case
+        kr, vr = O.gather_compact(k_exp, v_exp, want, w)
+        assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), case
+    _report("randomised_compress/worst_score_mismatch_frac", worst)
+
+
 def _margin_ok(s: torch.Tensor, idx: torch.Tensor, ulps=3) -> bool:
     """True if every pair of distinct selected score values, and the k-th vs the best rejected one,
     are more than `ulps` apart: then 1-ulp score noise cannot change the selection."""
