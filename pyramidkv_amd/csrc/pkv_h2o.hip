@@ -14,9 +14,12 @@
 // error of the window path's exp, and deliberately so: a score here is a sum over S >= 1000s of rounded
 // probabilities, so the rare rounding flips (1e-6 / 2^-9 per element) average out far below the model-dtype
 // resolution of the sum (measured against the oracle in tests/test_gpu_parity.py::test_h2o_*), while the
-// kernels are VALU-bound and the accurate exp costs 8 of ~18 vector instructions per S x S element.
-// Roofline: compute.  2*2*S^2*D*H flops per call on the matrix cores, plus ~60 VALU ops per S x S
-// element for the rounding chain / exp / division, which is what actually bounds it.
+// kernels are instruction-issue-bound and the accurate exp costs 8 vector instructions per S x S element.
+// Roofline: compute.  2*2*S^2*D*H flops per call on the matrix cores; what actually bounds it is the SIMD issue port,
+// shared by the MFMAs and the ~10 vector instructions per S x S element of the rounding chain / exp (a quarter-rate
+// transcendental) / accumulate: ~190 issue cycles per 16x16 output block against 64 cycles of matrix-pipe time.
+// Issuing the next subtile's MFMAs ahead of the current epilogue (software pipelining) changed nothing (12.45 ->
+// 12.26 ms at 192 VGPRs): the port, not the MFMA latency, is the limit.
 #include "pkv_common.hpp"
 #include "pkv_kernels.hpp"
 
@@ -43,6 +46,47 @@ __device__ __forceinline__ float logit_chain(float acc, const H2OParams& p) {
   float x = Elem<T>::to_f32(Elem<T>::from_f32(acc));                       // matmul output dtype (:544)
   x = scale_logit<T>(x, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);             // / math.sqrt(head_dim)
   return Elem<T>::to_f32(Elem<T>::from_f32(x));
+}
+
+// Four logits of one MFMA accumulator through the reference's two roundings.  bf16: the values travel as packed
+// pairs - one v_cvt_pk_bf16_f32 per two roundings, one shift / mask per unpack, the scale as a packed fp32
+// multiply (these kernels are VALU-bound: 13 -> ~10 vector-instruction equivalents per S x S element).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void logits4(const f32x4& acc, const H2OParams& p, float (&x)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) x[r] = logit_chain<T>(acc[r], p);
+}
+template <>
+__device__ __forceinline__ void logits4<BF16>(const f32x4& acc, const H2OParams& p, float (&x)[4]) {
+  uint32_t p01 = round_pack2<BF16>(acc[0], acc[1]);                        // matmul output dtype (:544)
+  uint32_t p23 = round_pack2<BF16>(acc[2], acc[3]);
+  f32x2 a = {__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u)};
+  f32x2 b = {__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)};
+  const f32x2 rc = {p.rcp_sqrt_d, p.rcp_sqrt_d};                           // / math.sqrt(head_dim): exact for bf16, see scale_logit
+  a = a * rc;
+  b = b * rc;
+  p01 = round_pack2<BF16>(a.x, a.y);
+  p23 = round_pack2<BF16>(b.x, b.y);
+  x[0] = __uint_as_float(p01 << 16); x[1] = __uint_as_float(p01 & 0xffff0000u);
+  x[2] = __uint_as_float(p23 << 16); x[3] = __uint_as_float(p23 & 0xffff0000u);
+}
+// round four fp32 probabilities to the model dtype and return their fp32 sum ((p0 + p1) + (p2 + p3))
+template <typename T>
+__device__ __forceinline__ float round_sum4(const float (&e)[4]) {
+  float pq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pq[r] = Elem<T>::to_f32(Elem<T>::from_f32(e[r]));
+  return (pq[0] + pq[1]) + (pq[2] + pq[3]);
+}
+template <>
+__device__ __forceinline__ float round_sum4<BF16>(const float (&e)[4]) {
+  const uint32_t p01 = round_pack2<BF16>(e[0], e[1]);
+  const uint32_t p23 = round_pack2<BF16>(e[2], e[3]);
+  const f32x2 lo = {__uint_as_float(p01 << 16), __uint_as_float(p23 << 16)};
+  const f32x2 hi = {__uint_as_float(p01 & 0xffff0000u), __uint_as_float(p23 & 0xffff0000u)};
+  const f32x2 s = lo + hi;                                                 // (p0 + p1), (p2 + p3)
+  return s.x + s.y;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -140,8 +184,7 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) acc = Mfma2<T>::run(kf[kk], qf[n][kk], acc);
         float x[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = logit_chain<T>(acc[r], p);
+        logits4<T>(acc, p, x);
         if (edge) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -158,9 +201,11 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
           m[n] = mn;
           mL[n] = (mn == -INFINITY) ? 0.f : -mn * L2E;
         }
-        const float c = mL[n];
-        Z[n] += (__builtin_amdgcn_exp2f(fmaf(x[0], L2E, c)) + __builtin_amdgcn_exp2f(fmaf(x[1], L2E, c))) +
-                (__builtin_amdgcn_exp2f(fmaf(x[2], L2E, c)) + __builtin_amdgcn_exp2f(fmaf(x[3], L2E, c)));
+        const f32x2 c2 = {mL[n], mL[n]}, l2 = {L2E, L2E};
+        const f32x2 y01 = __builtin_elementwise_fma(f32x2{x[0], x[1]}, l2, c2);
+        const f32x2 y23 = __builtin_elementwise_fma(f32x2{x[2], x[3]}, l2, c2);
+        Z[n] += (__builtin_amdgcn_exp2f(y01.x) + __builtin_amdgcn_exp2f(y01.y)) +
+                (__builtin_amdgcn_exp2f(y23.x) + __builtin_amdgcn_exp2f(y23.y));
       }
     }
     if (t + 1 < ntiles) stage_store(stg, tiles[(t + 1) & 1], tid);            // buffer last read in iteration t-1
@@ -239,18 +284,18 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) acc = Mfma2<T>::run(qf[kk], kf[n][kk], acc);   // D[query][key]
-        float pq[4];
+        float x[4], e[4];
+        logits4<T>(acc, p, x);                                 // keys < L never touch the masked corner
+        const f32x2 l2 = {L2E2, L2E2};
+        const f32x2 y01 = __builtin_elementwise_fma(f32x2{x[0], x[1]}, l2, f32x2{st[0].x, st[1].x});
+        const f32x2 y23 = __builtin_elementwise_fma(f32x2{x[2], x[3]}, l2, f32x2{st[2].x, st[3].x});
+        e[0] = __builtin_amdgcn_exp2f(y01.x); e[1] = __builtin_amdgcn_exp2f(y01.y);   // fp32 softmax (:553): exp(x - m) / Z
+        e[2] = __builtin_amdgcn_exp2f(y23.x); e[3] = __builtin_amdgcn_exp2f(y23.y);
+        if (tail) {                                            // wave-uniform, last tile only: rows past S contribute 0
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = logit_chain<T>(acc[r], p);           // keys < L never touch the masked corner
-          const float pr = __builtin_amdgcn_exp2f(fmaf(x, L2E2, st[r].x));   // fp32 softmax (:553): exp(x - m) / Z
-          pq[r] = Elem<T>::to_f32(Elem<T>::from_f32(pr));
+          for (int r = 0; r < 4; ++r) if (i0 + lg * 4 + r >= S) e[r] = 0.f;
         }
-        if (tail) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (i0 + lg * 4 + r >= S) pq[r] = 0.f;
-        }
-        col[n] += (pq[0] + pq[1]) + (pq[2] + pq[3]);           // sum over all rows, fp32 (:554)
+        col[n] += round_sum4<T>(e);                            // .to(dtype), sum over all rows in fp32 (:554)
       }
     }
     if (t + 1 < ntiles) {
