@@ -100,6 +100,21 @@ __device__ __forceinline__ float pkv_exp(float x) {
   return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 
+// pkv_exp on a pair: the multiply and the two FMAs of the range reduction are packed fp32 instructions (same IEEE
+// operations, same results as two scalar calls); the kernels that evaluate one exponential per logit are bound by the
+// SIMD issue port, where every instruction counts.
+typedef float pkv_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pkv_f32x2 pkv_exp_pair(pkv_f32x2 x) {
+  const pkv_f32x2 xc = {fmaxf(x.x, -104.0f), fmaxf(x.y, -104.0f)};
+  const pkv_f32x2 hi = {1.44269502162933349609375f, 1.44269502162933349609375f};       // fp32(log2 e)
+  const pkv_f32x2 lo = {1.92596299112661746e-8f, 1.92596299112661746e-8f};             // log2 e - hi
+  const pkv_f32x2 t = xc * hi;
+  const pkv_f32x2 n = {rintf(t.x), rintf(t.y)};
+  pkv_f32x2 f = __builtin_elementwise_fma(xc, hi, -n);
+  f = __builtin_elementwise_fma(xc, lo, f);
+  return pkv_f32x2{ldexpf(__builtin_amdgcn_exp2f(f.x), (int)n.x), ldexpf(__builtin_amdgcn_exp2f(f.y), (int)n.y)};
+}
+
 // correctly rounded x / c for a loop-invariant c (rc = RN(1/c)): one Newton-Markstein correction step.
 __device__ __forceinline__ float div_const(float x, float c, float rc) {
   const float q = x * rc;

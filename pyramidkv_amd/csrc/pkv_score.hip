@@ -277,12 +277,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const uint16_t h4[4] = {(uint16_t)(u[j].x & 0xffffu), (uint16_t)(u[j].x >> 16),
-                                (uint16_t)(u[j].y & 0xffffu), (uint16_t)(u[j].y >> 16)};
+        // two keys per packed instruction: x - M, exp, * (1/Z), round, accumulate (same operations as the scalar form)
+        const uint32_t uu[2] = {u[j].x, u[j].y};
+        const pkv_f32x2 mm = {M[j], M[j]}, rz = {RZ[j], RZ[j]}, ww = {wt[j], wt[j]};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pr = pkv_exp(Elem<T>::to_f32(h4[e]) - M[j]) * RZ[j];        // fp32 softmax (:326)
-          acc[e] += wt[j] * Elem<T>::to_f32(Elem<T>::from_f32(pr));               // .to(dtype); fp32 row accumulate (:327)
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const pkv_f32x2 x = {Elem<T>::to_f32((uint16_t)(uu[h2] & 0xffffu)), Elem<T>::to_f32((uint16_t)(uu[h2] >> 16))};
+          const pkv_f32x2 pr = pkv_exp_pair(x - mm) * rz;                           // fp32 softmax (:326)
+          const uint32_t pk2 = round_pack2<T>(pr.x, pr.y);                          // .to(dtype)
+          const pkv_f32x2 pv = {Elem<T>::to_f32((uint16_t)(pk2 & 0xffffu)), Elem<T>::to_f32((uint16_t)(pk2 >> 16))};
+          const pkv_f32x2 a2 = __builtin_elementwise_fma(ww, pv, pkv_f32x2{acc[2 * h2], acc[2 * h2 + 1]});   // fp32 row accumulate (:327)
+          acc[2 * h2] = a2.x;
+          acc[2 * h2 + 1] = a2.y;
         }
       }
     }
