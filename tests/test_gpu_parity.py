@@ -467,6 +467,36 @@ def test_adakv_cluster_metadata_and_consistency(P):
     assert torch.equal(kf2.cpu(), k2.reshape(-1, 128)) and cl2.head_lens.cpu().tolist() == [40, 40]
 
 
+def test_adakv_randomised_configs(P):
+    """24 seeded random Ada-SnapKV configurations (heads, S, window, pooling, budget, floor, normalize, dtype): the head
+    budgets computed on the device from the kernel's own scores equal the oracle's budget arithmetic on those same
+    scores, metadata is consistent, and the flat K/V is the exact gather of each head's first cap_h sorted tokens."""
+    rng = np.random.default_rng(11)
+    for case in range(24):
+        H = int(rng.choice([2, 4, 8, 16, 32]))
+        w = int(rng.choice([4, 8, 8, 16]))
+        S = int(rng.integers(w + 300, 6000))
+        cap = int(rng.integers(w + 8, min(S - w, 600)))
+        pool = str(rng.choice(["maxpool", "avgpool"]))
+        ks = int(rng.choice([1, 5, 7]))
+        floor = float(rng.choice([0.0, 0.2, 0.5, 1.0]))
+        norm = bool(rng.integers(0, 2))
+        dt = "bf16" if case % 2 else "fp16"
+        q, k, v = make_qkv(1, H, S, 128, dt, "gauss", 900 + case)
+        cl = P.AdaKVCluster(window_size=w, kernel_size=ks, pooling=pool, max_capacity_prompt=cap, floor=floor, normalize=norm)
+        kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
+        sg = P.ops.score_window(q.to(DEV), k.to(DEV), w, pool, ks, "mean").cpu()[0]            # [H, L]
+        sidx, caps = O.adakv_head_capacity(sg[None], cap - w, floor, norm)
+        sidx, caps = sidx[0], caps[0].tolist()
+        lens = cl.head_lens.cpu().tolist()
+        assert lens == [int(c) + w for c in caps], (case, lens, caps)
+        assert int(cl.klen_sum) == sum(lens) == kf.shape[0] and cl.max_seqlen_k == max(lens)
+        assert cl.cu_klen.cpu().tolist() == [0] + np.cumsum(lens).tolist()
+        per_head = [sidx[h, :int(caps[h])] for h in range(H)]
+        kr, vr, _ = O._flat_gather(k, v, per_head, w)
+        assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr), case
+
+
 def test_headkv_cluster(P):
     H, S, w, cap = 4, 512, 8, 64
     q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 61)
