@@ -345,6 +345,24 @@ def test_compress_randomised_configs(P):
     _report("randomised_compress/worst_score_mismatch_frac", worst)
 
 
+@pytest.mark.parametrize("S,w,kk,pool,ks", [(9, 8, 1, "maxpool", 7), (10, 8, 2, "avgpool", 5), (3, 1, 2, "maxpool", 1), (2, 1, 1, "avgpool", 3),
+                                           (130, 64, 66, "maxpool", 17), (129, 1, 128, "avgpool", 17), (257, 32, 1, "maxpool", 3)])
+def test_compress_degenerate_shapes(P, S, w, kk, pool, ks):
+    """Smallest legal problems (one past token, k = L, window = S - 1, widest pool on a shorter row): same checks as the
+    randomised configurations."""
+    for dt in ("bf16", "fp16"):
+        q, k, v = make_qkv(2, 3, S, 128, dt, "gauss", S * 7 + w)
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk, pool, ks, return_indices=True)
+        sg = P.ops.score_window(qd, kd, w, pool, ks)
+        so = O.pool_scores(O.window_scores(q, k, w), pool, ks)
+        assert int(np.abs(ord16(sg.cpu()).astype(np.int64) - ord16(so).astype(np.int64)).max()) <= 1
+        want = O.topk_canonical(sg.cpu(), kk)
+        assert torch.equal(idx.cpu().long(), want)
+        kr, vr = O.gather_compact(k, v, want, w)
+        assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+
+
 def _margin_ok(s: torch.Tensor, idx: torch.Tensor, ulps=3) -> bool:
     """True if every pair of distinct selected score values, and the k-th vs the best rejected one,
     are more than `ulps` apart: then 1-ulp score noise cannot change the selection."""
