@@ -31,7 +31,6 @@ int logits_nt() { static int t = env_int("PKV_LOGITS_NT", 0); return t; }
 int logits_v2() { static int t = env_int("PKV_LOGITS_V2", 1); return t; }
 int logits_v2_nt() { static int t = env_int("PKV_LOGITS_NT", 1); return t; }
 int logits_v2_wgs() { static int t = env_int("PKV_LOGITS_V2_WGS", 0); return t; }   // target workgroup count, 0 = 8 per CU
-int finalize_nt() { static int t = env_int("PKV_FINALIZE_NT", 0); return t; }
 int logits_ablate() { static int t = env_int("PKV_LOGITS_ABLATE", 0); return t; }   // measurement only: wrong results
 
 inline int hip_fail(hipError_t e) { g_last_hip = (int)e; return PKV_ERR_HIP; }
@@ -172,7 +171,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   fp.reduce = d->reduce;
   fp.cmax = want_cmax ? ws + L.off_cmax : nullptr; fp.cmax_stride = L.Lp / 8;
   fp.trace = g_topk_trace ? g_topk_trace + 8 : nullptr;
-  fp.wgtrace = g_wg_trace; fp.nt = finalize_nt();
+  fp.wgtrace = g_wg_trace;
   {
     ProfScope ps(PKV_K_FINALIZE, st, true);
     hipError_t e = launch_finalize(d->dtype, fp, st);

@@ -50,7 +50,6 @@ struct FinalizeParams {
   int64_t cmax_stride;
   unsigned long long* trace;   // debug: phase timestamps of block (0,0) (may be null)
   unsigned long long* wgtrace;
-  int nt;                // bit 0: nontemporal logits loads, bit 1: nontemporal score stores (PKV_FINALIZE_NT)
 };
 
 struct TopkParams {

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
       if (c < C) *reinterpret_cast<uint2*>(tile + c * LROW + key0) = make_uint2(p01, p23);
     }
   }
-  if (p.ablate >= 1 && p.ablate <= 3) return;   // measurement aid: no statistics / logits store
+  if (p.ablate >= 1) return;   // measurement aid: no statistics / logits store
   __syncthreads();
 
   // ---- per-row tile statistics + coalesced 16-B store of the logits tile (CH lanes per row) ----
@@ -170,19 +170,15 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 #pragma unroll
     for (int o = CH / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));   // CH-lane group = one row
     float l = 0.f;
-    if (p.ablate != 5) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float t = pkv_exp(xv[e] - m);
-        l += (s0 + e < S && m != -INFINITY) ? t : 0.f;
-      }
-#pragma unroll
-      for (int o = CH / 2; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
-      if (chunk == 0) p.partial[(rowbase + row) * p.nT + t_idx] = make_float2(m, l);
+    for (int e = 0; e < 8; ++e) {
+      const float t = pkv_exp(xv[e] - m);
+      l += (s0 + e < S && m != -INFINITY) ? t : 0.f;
     }
-    if (p.ablate == 4) continue;
-    if (p.ablate == 6) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, u.v), reinterpret_cast<u32x4*>(lg_out + (rowbase + row) * (int64_t)p.Sp + s0));
-    else *reinterpret_cast<uint4*>(lg_out + (rowbase + row) * (int64_t)p.Sp + s0) = u.v;
+#pragma unroll
+    for (int o = CH / 2; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    if (chunk == 0) p.partial[(rowbase + row) * p.nT + t_idx] = make_float2(m, l);
+    *reinterpret_cast<uint4*>(lg_out + (rowbase + row) * (int64_t)p.Sp + s0) = u.v;
   }
   if (p.wgtrace && tid == 0) {
     const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -269,7 +265,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
       for (int j = 0; j < 8; ++j) {
         const int r = rb + j < w ? rb + j : w - 1;
         const u32x2* lp2 = reinterpret_cast<const u32x2*>(lgp + (int64_t)r * p.Sp);
-        const u32x2 t2 = (p.nt & 1) ? __builtin_nontemporal_load(lp2) : *lp2;
+        const u32x2 t2 = *lp2;
         u[j] = make_uint2(t2.x, t2.y);
         M[j] = rowM[r];
         RZ[j] = rowS[r];
@@ -372,8 +368,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   ro.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
   ro.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
   uint16_t* out = reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride + s0;
-  if (p.nt & 2) __builtin_nontemporal_store(u32x2{ro.x, ro.y}, reinterpret_cast<u32x2*>(out));
-  else *reinterpret_cast<uint2*>(out) = ro;      // stride % 8 == 0, s0 % 4 == 0, stride >= roundup(L,8): aligned, in bounds
+  *reinterpret_cast<uint2*>(out) = ro;      // stride % 8 == 0, s0 % 4 == 0, stride >= roundup(L,8): aligned, in bounds
   if (p.trace && tid == 2 && blockIdx.x == 1 && bh == 0) p.trace[4] = (unsigned long long)clock64();
 #undef PKV_FSTAMP
 }
