@@ -232,17 +232,22 @@ class _FlatPolicy:
         self.cu_offset = None
         self.cu_headlens = None
 
+    _CONST = {}     # (num_heads, device) -> the four read-only index vectors (the decode step only adds cu_offset to cu_klen)
+
     def _init_metadata(self, num_heads, head_lens, cu_klen, klen_sum, max_seqlen_k, device):
         self.head_lens = head_lens                                                   # int32 [H]          :684
         self.klen_sum = klen_sum                                                     #                    :685
         self.max_seqlen_k = max_seqlen_k                                             #                    :686
         self.cu_headlens = cu_klen[1:].clone()                                       # inclusive prefix   :687
         self.cu_klen = cu_klen                                                       # int32 [H+1]        :689-691
-        self.layer_qlens = torch.ones(num_heads, dtype=torch.int32, device=device)   #                    :692
+        key = (num_heads, str(device))
+        const = _FlatPolicy._CONST.get(key)
+        if const is None:            # built once per geometry: four tiny launches less on every prefill call
+            ar = torch.arange(0, num_heads + 1, dtype=torch.int32, device=device)
+            const = (torch.ones(num_heads, dtype=torch.int32, device=device), ar, ar.clone(), ar[1:].clone())
+            _FlatPolicy._CONST[key] = const
+        self.layer_qlens, self.cu_qlen, self.cu_offset, self.cu_head_offset = const   # :692, :694-698
         self.qlen_sum = num_heads
-        self.cu_qlen = torch.arange(0, num_heads + 1, dtype=torch.int32, device=device)   # :694-696
-        self.cu_offset = torch.arange(0, num_heads + 1, dtype=torch.int32, device=device)  # :697
-        self.cu_head_offset = torch.arange(1, num_heads + 1, dtype=torch.int32, device=device)  # :698
 
     def _scores(self, key_states, query_states):
         """calcul_attn_sore (:647-672): mean over the window rows, then pooling."""
