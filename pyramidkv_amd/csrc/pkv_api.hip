@@ -420,6 +420,7 @@ int pkv_sort_rows(int32_t dtype, int32_t rows, int32_t L, const void* scores, in
   sp.sorted_idx = sorted_idx; sp.sorted_val = sorted_val;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_SORT, st);
+  sp.trace = g_topk_trace;
   hipError_t e = launch_sort_rows(dtype, rows, sp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }

@@ -76,6 +76,7 @@ struct SortParams {
   int L, n;              // n = power of two >= L
   int32_t* sorted_idx;   // [rows][L]
   void* sorted_val;      // [rows][L] or null
+  unsigned long long* trace;   // debug: phase stamps of row 0 (may be null)
 };
 
 struct GatherParams {

@@ -592,7 +592,11 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
   uint16_t* ov = p.sorted_val ? reinterpret_cast<uint16_t*>(p.sorted_val) + (int64_t)row * L : nullptr;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
+#define PKV_SSTAMP(i) do { if (p.trace && tid == 0 && row == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
+  PKV_SSTAMP(0);
   for (int i = tid; i < L; i += TK_THREADS) comp[i] = (order_key<T>(src[i]) << 16) | (uint32_t)i;
+  __syncthreads();
+  PKV_SSTAMP(1);
   for (int pass = 0; pass < 2; ++pass) {
     for (int i = tid; i < TK_WAVES * 256; i += TK_THREADS) table[i] = 0;
     __syncthreads();
@@ -606,6 +610,7 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
       if (valid && (peers & lt) == 0ull) table[wave * 256 + d] += (uint32_t)__popcll(peers);   // group leader
     }
     __syncthreads();
+    PKV_SSTAMP(2 + pass * 4);
     if (tid < 256) {                                          // per digit: exclusive prefix over the 16 waves
       uint32_t run = 0;
 #pragma unroll
@@ -626,6 +631,7 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
     __syncthreads();
     for (int i = tid; i < TK_WAVES * 256; i += TK_THREADS) table[i] += tot[i & 255];   // absolute base of (wave, digit)
     __syncthreads();
+    PKV_SSTAMP(3 + pass * 4);
     // sweep B: same ranking against the absolute bases: output positions come out directly (stable)
     for (int e = 0; e < epw; ++e) {
       const int i = wave * epw * 64 + e * 64 + lane;
@@ -648,11 +654,14 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
         }
       }
     }
+    __syncthreads();
+    PKV_SSTAMP(4 + pass * 4);
     if (pass == 0) {
       __threadfence_block();
       __syncthreads();
       for (int i = tid; i < L; i += TK_THREADS) comp[i] = __builtin_nontemporal_load(buf + i);   // back in list order
       __syncthreads();
+      PKV_SSTAMP(5);
     }
   }
 }
