@@ -416,7 +416,7 @@ int pkv_sort_rows(int32_t dtype, int32_t rows, int32_t L, const void* scores, in
   if (L > 32768) return PKV_ERR_UNSUPPORTED;
   SortParams sp;
   sp.scores = scores; sp.scores_stride = scores_stride; sp.L = L;
-  sp.n = (L + 3) & ~3;   // composites kept in LDS (4 B each)
+  sp.n = (L + 7) & ~7;   // raw values + index permutation kept in LDS (2 x 2 B each; keeps the tables 16-B aligned)
   sp.sorted_idx = sorted_idx; sp.sorted_val = sorted_val;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_SORT, st);

@@ -577,35 +577,46 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
   return peers;
 }
 
+// Stable descending sort of one row per workgroup (keys = 16-bit scores, ties by ascending index): two LSD radix passes
+// (low byte, high byte) ranked with match-any ballots.  Everything between the passes stays in LDS: the row's raw 16-bit
+// values (the digits are recomputed from them, and they are what the value output needs) and a 16-bit index permutation
+// written by pass 0 and walked by pass 1; only the final (index, value) scatter goes to memory.
 template <typename T>
 __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* comp = reinterpret_cast<uint32_t*>(smem);                   // [n] composites, list order
-  uint32_t* table = comp + p.n;                                         // [16][256]
+  uint16_t* val = reinterpret_cast<uint16_t*>(smem);                    // [n] raw scores, natural order
+  uint16_t* perm = val + p.n;                                           // [n] indices in pass-0 order
+  uint32_t* table = reinterpret_cast<uint32_t*>(perm + p.n);            // [16][256]
   uint32_t* tot = table + TK_WAVES * 256;                               // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = blockIdx.x;
   const int L = p.L;
   const int epw = (L + TK_THREADS - 1) / TK_THREADS;         // 64-element steps per wave
   const uint16_t* src = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)row * p.scores_stride;
-  uint32_t* buf = reinterpret_cast<uint32_t*>(p.sorted_idx + (int64_t)row * L);
+  int32_t* oi = p.sorted_idx + (int64_t)row * L;
   uint16_t* ov = p.sorted_val ? reinterpret_cast<uint16_t*>(p.sorted_val) + (int64_t)row * L : nullptr;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
 #define PKV_SSTAMP(i) do { if (p.trace && tid == 0 && row == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
   PKV_SSTAMP(0);
-  for (int i = tid; i < L; i += TK_THREADS) comp[i] = (order_key<T>(src[i]) << 16) | (uint32_t)i;
+  for (int i = tid; i < L; i += TK_THREADS) val[i] = src[i];
   __syncthreads();
   PKV_SSTAMP(1);
   for (int pass = 0; pass < 2; ++pass) {
+    // list element j of this pass: pass 0 = natural order, pass 1 = pass 0's output order
+    auto element = [&](int j, uint32_t& idx, uint32_t& d) {
+      idx = pass == 0 ? (uint32_t)j : (uint32_t)perm[j];
+      const uint32_t key = order_key<T>(val[idx]);
+      d = 255u - ((key >> (8 * pass)) & 255u);                          // ascending d == descending key
+    };
     for (int i = tid; i < TK_WAVES * 256; i += TK_THREADS) table[i] = 0;
     __syncthreads();
     // sweep A: per-wave digit counts (wave w owns the contiguous list segment [w*epw*64, (w+1)*epw*64))
     for (int e = 0; e < epw; ++e) {
-      const int i = wave * epw * 64 + e * 64 + lane;
-      const bool valid = i < L;
-      const uint32_t c = valid ? comp[i] : 0u;
-      const uint32_t d = 255u - ((c >> (16 + 8 * pass)) & 255u);        // ascending d == descending key
+      const int j = wave * epw * 64 + e * 64 + lane;
+      const bool valid = j < L;
+      uint32_t idx = 0, d = 0;
+      if (valid) element(j, idx, d);
       const uint64_t peers = match_digit(d, valid);
       if (valid && (peers & lt) == 0ull) table[wave * 256 + d] += (uint32_t)__popcll(peers);   // group leader
     }
@@ -634,10 +645,10 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
     PKV_SSTAMP(3 + pass * 4);
     // sweep B: same ranking against the absolute bases: output positions come out directly (stable)
     for (int e = 0; e < epw; ++e) {
-      const int i = wave * epw * 64 + e * 64 + lane;
-      const bool valid = i < L;
-      const uint32_t c = valid ? comp[i] : 0u;
-      const uint32_t d = 255u - ((c >> (16 + 8 * pass)) & 255u);
+      const int j = wave * epw * 64 + e * 64 + lane;
+      const bool valid = j < L;
+      uint32_t idx = 0, d = 0;
+      if (valid) element(j, idx, d);
       const uint64_t peers = match_digit(d, valid);
       const uint32_t before = (uint32_t)__popcll(peers & lt);
       uint32_t prev = 0;
@@ -646,24 +657,17 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
       if (valid) {
         const uint32_t pos = prev + before;
         if (pass == 0) {
-          buf[pos] = c;                                       // composites ping-pong through the output buffer
+          perm[pos] = (uint16_t)idx;                          // stays in LDS
         } else {
-          const uint32_t idx = c & 0xffffu;
-          buf[pos] = idx;
-          if (ov) ov[pos] = src[idx];
+          oi[pos] = (int32_t)idx;
+          if (ov) ov[pos] = val[idx];
         }
       }
     }
     __syncthreads();
     PKV_SSTAMP(4 + pass * 4);
-    if (pass == 0) {
-      __threadfence_block();
-      __syncthreads();
-      for (int i = tid; i < L; i += TK_THREADS) comp[i] = __builtin_nontemporal_load(buf + i);   // back in list order
-      __syncthreads();
-      PKV_SSTAMP(5);
-    }
   }
+#undef PKV_SSTAMP
 }
 
 hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st) {
@@ -717,7 +721,7 @@ hipError_t launch_topk_merge_finish(int rows, int k, const int32_t* cand_idx, in
 
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st) {
   auto fn = dtype == 0 ? sort_rows_kernel<BF16> : sort_rows_kernel<F16>;
-  const size_t lds = (size_t)p.n * 4 + (size_t)TK_WAVES * 256 * 4 + 256 * 4;
+  const size_t lds = (size_t)p.n * 4 + (size_t)TK_WAVES * 256 * 4 + 256 * 4;     // 2 x 16-bit per element + tables
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -12,5 +12,5 @@ P.ops.sort_rows(s)
 torch.cuda.synchronize()
 N.lib.pkv_debug_topk_trace(None)
 t = buf.cpu().tolist()
-names = ["start", "composites", "p0_sweepA", "p0_prefix", "p0_sweepB", "p0_reload", "p1_sweepA", "p1_prefix", "p1_sweepB"]
-print(json.dumps({names[i]: t[i] - t[0] for i in range(9)}))
+names = {0: "start", 1: "row_in_lds", 2: "p0_sweepA", 3: "p0_prefix", 4: "p0_sweepB", 6: "p1_sweepA", 7: "p1_prefix", 8: "p1_sweepB"}
+print(json.dumps({n: t[i] - t[0] for i, n in names.items()}))
