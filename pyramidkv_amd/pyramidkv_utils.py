@@ -263,9 +263,13 @@ class _FlatPolicy:
         self._init_metadata(num_heads, head_lens, cu, q_len * num_heads, q_len, dev)  # :701
         return key_states.reshape(-1, head_dim), value_states.reshape(-1, head_dim)   # :703
 
-    def _flat_from_capacity(self, key_states, value_states, sorted_idx, cap_dev, num_heads):
+    def _flat_from_capacity(self, key_states, value_states, sorted_idx, cap_dev, num_heads, caps_host=None):
+        """Flat gather + metadata.  The boundary exposes klen_sum / max_seqlen_k as Python ints (:685-686), which needs the
+        capacities on the host: HeadKV knows them already (``caps_host``), Ada-SnapKV reads them back (one host sync, as the
+        reference's ``.item()`` at :718; launching the gather ahead of that read-back into bound-sized buffers was measured
+        and gains nothing)."""
         head_lens, cu = ops.ada_metadata(cap_dev, self.window_size)
-        caps = cap_dev.tolist()          # host sync: the boundary exposes klen_sum/max_seqlen_k as ints (:685-686)
+        caps = caps_host if caps_host is not None else cap_dev.tolist()
         klen_sum = sum(caps) + num_heads * self.window_size
         max_cap = max(caps)
         kf, vf = ops.gather_flat(key_states, value_states, sorted_idx, cap_dev, cu, self.window_size, klen_sum,
@@ -328,7 +332,7 @@ class HeadKVCluster(_FlatPolicy):
         sorted_idx, _ = ops.sort_rows(attn_score[0], want_values=False)              # :840
         caps = [min(int(self.head_adaptive_capacity[self.layer_idx][h]), L) for h in range(num_heads)]  # :855 slice
         cap = torch.tensor(caps, dtype=torch.int32, device=key_states.device)
-        return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads)
+        return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, caps_host=caps)
 
 
 # ------------------------------------------------------------------------------------------------
