@@ -236,18 +236,19 @@ def test_varlen_decode_attention_matches_per_head_loop():
         assert torch.allclose(got[h], p @ vf[a:b], atol=1e-6)
 
 
+@pytest.mark.parametrize("family", ["llama", "mistral"])
 @pytest.mark.parametrize("method", ["adakv", "headkv"])
-def test_flat_cache_methods_generate(patched, method):
+def test_flat_cache_methods_generate(patched, method, family):
     """replace_llama('adakv'|'headkv') with a DynamicCacheSplitHeadFlatten: prompt logits untouched, per-layer flat
     lengths = sum_h(cap_h + w), decode appends one row per head and keeps positions running."""
     import pyramidkv_amd as P
-    model = _tiny("llama")
+    model = _tiny(family)
     S, new, cap, w = 200, 5, 64, 8
     ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
         base = model(ids).logits
     patched._cluster_module = _flat_module()
-    patched.replace_llama(method)
+    (patched.replace_llama if family == "llama" else patched.replace_mistral)(method)
     H, Lyr = model.config.num_attention_heads, model.config.num_hidden_layers
     for layer in model.model.layers:
         c = layer.self_attn.config
