@@ -8,15 +8,21 @@ Workload (BASELINE.json metric: "prefill tokens/s + KV-compress ms at S=32k budg
   Llama-3-8B attention shapes H=32, D=128, S=32768, bf16, synthetic N(0,1) Q/K/V resident in HBM.
   One STEP = the compress work of one model prefill: 32 update_kv calls, layer budgets 234..17
   (pyramidkv_utils.py:205-215), each on a [B,H,S,D] batch.  value = B*S*steps / time.
-Multi-GPU: head-sharded (rank r owns H/N heads of B=N sequences: per-GPU bytes fixed => weak scaling)
-with one RCCL all-gather of the selected indices per layer (pyramidkv_amd/dist.py).
+Multi-GPU: head-sharded, one RCCL all-gather of the selected indices per layer (pyramidkv_amd/dist.py).  Two legs are
+timed and reported in `scaling_legs`: "weak" (rank r owns H/N heads of B = N sequences: per-GPU bytes fixed; this is
+`value`) and "strong_config4" (BASELINE config 4: ONE 32k sequence, H/N heads per GPU).
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel = the K scan),
-`roofline_kernels` (every kernel, incl. the gather-compaction the north star targets) and
-`cpu_baseline` (the oracle = the reference's eager CPU path, timed on this node's host cores).
+Rank 0 prints ONE JSON line with the contract fields plus
+  `roofline`          dominant kernel (the K scan) of the headline workload,
+  `roofline_kernels`  every kernel of the headline workload AND the north-star kernel at its target configuration:
+                      `gather_cap2048_B1` / `gather_cap2048_B8` (SnapKV budget 2048, S = 32768; 67.1 MB x B),
+  `grid`              single update_kv calls at B in {1,8} x budget in {128,2048} (device time per kernel),
+  `gpu_eager_baseline` the reference's eager op sequence (oracle restatement) run by PyTorch-ROCm on this same GPU,
+  `cpu_baseline`      the same op sequence on this node's host cores.
 """
 import argparse
 import contextlib
+import hashlib
 import io
 import json
 import os
@@ -31,6 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 NUM_LAYERS = 32
+D, W, E = 128, 8, 2
 
 
 def parse():
@@ -41,11 +48,11 @@ def parse():
     ap.add_argument("--seq", type=int, default=32768)
     ap.add_argument("--budget", type=int, default=128)
     ap.add_argument("--heads", type=int, default=32)
-    ap.add_argument("--batch", type=int, default=0, help="0 = one sequence per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="0 = one sequence per GPU (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--policy", default="pyramidkv", choices=["pyramidkv", "snapkv"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip grid / gqa / gpu_eager_baseline / strong leg")
     ap.add_argument("--cpu-layers", type=int, default=32, help="layer-calls per CPU-baseline pass (32 = the whole step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work spent on the cpu_baseline sample")
     return ap.parse_args()
@@ -64,14 +71,32 @@ def layer_budgets(P, policy, cap, w, S):
     return ks
 
 
+def kernel_src_sha16():
+    """Identity of the kernel sources a PMC traffic profile belongs to (profiles/*/pmc_traffic.json records it)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pyramidkv_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def make_sets(B, Hl, S, dt, dev, seed, nsets):
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    sets = []
+    for _ in range(nsets):
+        sets.append(tuple(torch.randn(B, Hl, S, D, generator=gen, device=dev, dtype=torch.float32).to(dt) for _ in range(3)))
+    return sets
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run, any world size
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     import pyramidkv_amd as P
     from pyramidkv_amd import _native as N, dist as pdist
 
@@ -81,71 +106,68 @@ def main():
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    dist = None
+    if launched:           # also at world size 1: the RCCL communicator and the all-gather are exercised with nranks = 1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+    collective = dist is not None
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
-    e = 2
-    S, H, D, w, cap = a.seq, a.heads, 128, 8, a.budget
-    B = a.batch if a.batch > 0 else world
+    S, H, cap = a.seq, a.heads, a.budget
     h0, h1 = pdist.shard_heads(H, rank, world)
     Hl = h1 - h0
-    ks = layer_budgets(P, a.policy, cap, w, S)
-
-    # synthetic inputs, resident in HBM before the timed region.  NSETS distinct (Q,K,V) sets are cycled
-    # over the layers so that a layer never finds its K in the 256 MB Infinity Cache from the previous call.
-    NSETS = 4
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    sets = []
-    for _ in range(NSETS):
-        q = torch.randn(B, Hl, S, D, generator=gen, device=dev, dtype=torch.float32).to(dt)
-        k = torch.randn(B, Hl, S, D, generator=gen, device=dev, dtype=torch.float32).to(dt)
-        v = torch.randn(B, Hl, S, D, generator=gen, device=dev, dtype=torch.float32).to(dt)
-        sets.append((q, k, v))
-
-    def one_step():
-        # the one exchange step of the path (indices, KBs) is issued asynchronously: layer i+1's update_kv does not
-        # depend on layer i's gathered indices, so the latency-bound collective overlaps with it; at most two are
-        # in flight and all are waited for (on the stream) before the step ends
-        outs, pending = None, []
-        for layer in range(NUM_LAYERS):
-            q, k, v = sets[layer % NSETS]
-            kc, vc, idx = P.ops.compress(q, k, v, w, ks[layer], "maxpool", 7, return_indices=True)
-            if world > 1:
-                pending.append(pdist.allgather_indices_async(idx))
-                if len(pending) > 2:
-                    idx = pending.pop(0).wait()
-            outs = (kc, vc, idx)
-        for h in pending:
-            outs = (outs[0], outs[1], h.wait())
-        return outs
+    ks = layer_budgets(P, a.policy, cap, W, S)
+    NSETS = 4        # distinct (Q,K,V) sets cycled over the layers: a layer never finds its K in the 256 MB Infinity Cache
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    def timed_leg(B, steps, warmup, sets):
+        def one_step():
+            # the one exchange step of the path (indices, KBs) is issued asynchronously: layer i+1's update_kv does not
+            # depend on layer i's gathered indices, so the latency-bound collective overlaps with it; at most two are
+            # in flight and all are waited for (on the stream) before the step ends
+            outs, pending = None, []
+            for layer in range(NUM_LAYERS):
+                q, k, v = sets[layer % len(sets)]
+                kc, vc, idx = P.ops.compress(q, k, v, W, ks[layer], "maxpool", 7, return_indices=True)
+                if collective:
+                    pending.append(pdist.allgather_indices_async(idx, force=True))
+                    if len(pending) > 2:
+                        idx = pending.pop(0).wait()
+                outs = (kc, vc, idx)
+            for h in pending:
+                outs = (outs[0], outs[1], h.wait())
+            return outs
+
+        for _ in range(warmup):
+            one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None and world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, one_step
+
+    # ---- headline leg: weak scaling (B = N unless --batch) ----
+    B = a.batch if a.batch > 0 else world
+    sets = make_sets(B, Hl, S, dt, dev, 1234 + rank, NSETS)
+    el, one_step = timed_leg(B, a.steps, a.warmup, sets)
     ms_per_step = el / a.steps * 1e3
     tokens_per_s = B * S * a.steps / el
 
-    # ---- per-kernel device time over the same K steps (hipEvent pairs recorded inside libpkv) ----
+    # ---- per-kernel device time over the same K steps (events on the dispatches, inside libpkv) ----
     N.prof_enable(True)
     N.prof_read(reset=True)
     for _ in range(a.steps):
@@ -154,80 +176,187 @@ def main():
     prof = N.prof_read(reset=True)
     N.prof_enable(False)
 
-    def rl(name, bytes_per_launch):
-        ms, n = prof[name]
+    def rl(prof_, name, bytes_per_launch, label=None):
+        ms, n = prof_[name]
         if n == 0:
             return None
         avg_ms = ms / n
         ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"kernel": label or name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_ms * 1e3, 2),
                 "launches": int(n), "algorithmic_bytes": int(bytes_per_launch)}
 
-    rows_mean = sum(k + w for k in ks) / NUM_LAYERS
-    kernels = {
-        # K read once + the w query rows (S*D*e per head)
-        "logits": rl("logits", B * Hl * (S * D * e + w * D * e)),
-        # logits [w][S] read once, pooled scores written
-        "finalize": rl("finalize", B * Hl * (w * S * e + (S - w) * e)),
-        "topk": rl("topk", B * Hl * ((S - w) * e + (sum(ks) / NUM_LAYERS) * 4)),
-        # the north-star kernel: 2 tensors x (k+w) rows x D x e x (read+write), mean over the 32 layer budgets
-        "gather": rl("gather", 4 * rows_mean * D * e * B * Hl),
-    }
+    def alg_bytes(B_, Hl_, S_, k_mean):
+        n = B_ * Hl_
+        return {
+            "logits": n * (S_ * D * E + W * D * E),                      # K read once + the w query rows
+            "finalize": n * (W * S_ * E + (S_ - W) * E),                 # logits [w][S] read once, pooled scores written
+            "topk": n * ((S_ - W) * E + k_mean * 4),
+            "gather": 4 * (k_mean + W) * D * E * n,                      # 2 tensors x (k+w) rows x D x e x (read+write)
+        }
+
+    alg = alg_bytes(B, Hl, S, sum(ks) / NUM_LAYERS)
+    kernels = {k_: rl(prof, k_, v_) for k_, v_ in alg.items()}
     kernels = {k_: v_ for k_, v_ in kernels.items() if v_}
-    # HBM traffic per launch from rocprofv3 PMC passes of this same command (tools/pmc_summary.py writes the file)
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and a.seq == 32768 and a.budget == 128 and B == 1:
+    # HBM traffic per launch from rocprofv3 PMC passes (tools/pmc_summary.py).  Only attached when the profile was taken
+    # from exactly these kernel sources and this workload; otherwise the field stays null instead of going stale.
+    src_id = kernel_src_sha16()
+    for pmc_path in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         pmc = json.load(open(pmc_path))
-        for k_, v_ in kernels.items():
-            if k_ in pmc.get("kernels", {}):
-                v_["traffic"] = pmc["kernels"][k_].get("hbm_bytes_per_launch")
+        if pmc.get("kernel_src_sha16") == src_id and a.seq == 32768 and a.budget == 128 and B == 1 and world == 1:
+            for k_, v_ in kernels.items():
+                if k_ in pmc.get("kernels", {}):
+                    v_["traffic"] = pmc["kernels"][k_].get("hbm_bytes_per_launch")
+                    v_["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+            break
 
     out = {
         "metric": "prefill tokens/s through KV-compress (PyramidKV budget=%d, S=%d, Llama-3-8B shapes)" % (cap, S),
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "kv_compress_ms_per_layer": round(ms_per_step / NUM_LAYERS, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if a.batch == 0 else "strong", "vs_baseline": None, "dtype": a.dtype,
+        "data": "synthetic",
         "config": {"workload": "%s budget=%d window=8 maxpool7, 32 layer-calls/step, [B=%d,H=%d,S=%d,D=128] %s"
                                % (a.policy, cap, B, H, S, a.dtype),
                    "global_batch": B, "seq_len": S, "heads_per_gpu": Hl,
-                   "parallelism": "head-shard x%d + 1 all-gather(indices)/layer" % world if world > 1 else "single GPU"},
+                   "parallelism": ("head-shard x%d + 1 RCCL all-gather(indices)/layer" % world) if collective else "single GPU",
+                   "collective_backend": (backend if collective else None)},
         "roofline": kernels.get("logits"),
         "roofline_kernels": kernels,
+        "kernel_src_sha16": src_id,
     }
+    # whole-call effective bandwidth: all algorithmic bytes of a call / its wall time
+    out["call_effective"] = {"GBps": round(sum(alg.values()) / (ms_per_step / NUM_LAYERS * 1e-3) / 1e9, 1),
+                             "frac_of_8TBps": round(sum(alg.values()) / (ms_per_step / NUM_LAYERS * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del sets
+    torch.cuda.empty_cache()
 
-    # extra (not `value`): the same workload when K/V really are repeat_kv output of 8 KV heads (Llama-3-8B /
-    # Mistral-7B) and the caller opts into reading one head per GQA group (config.gqa_dedup)
-    if world == 1 and not a.no_extras and Hl % 4 == 0:
-        gsets = []
-        for (q, k, v) in sets:
-            k4 = k[:, ::4][:, :, None].expand(B, Hl // 4, 4, S, D).reshape(B, Hl, S, D).contiguous()
-            v4 = v[:, ::4][:, :, None].expand(B, Hl // 4, 4, S, D).reshape(B, Hl, S, D).contiguous()
-            gsets.append((q, k4, v4))
+    # ---- second multi-GPU leg: BASELINE config 4 = ONE 32k sequence, H/N heads per GPU (strong scaling) ----
+    if world > 1 and a.batch == 0 and not a.no_extras:
+        ssets = make_sets(1, Hl, S, dt, dev, 99 + rank, NSETS)
+        sel, _ = timed_leg(1, a.steps, 1, ssets)
+        out["scaling_legs"] = {
+            "weak": {"global_batch": B, "tokens_per_s": round(tokens_per_s, 1), "ms_per_step": round(ms_per_step, 4),
+                     "note": "B = N sequences, H/N heads of each per GPU: per-GPU bytes constant (this is `value`)"},
+            "strong_config4": {"global_batch": 1, "tokens_per_s": round(S * a.steps / sel, 1),
+                               "ms_per_step": round(sel / a.steps * 1e3, 4),
+                               "kv_compress_ms_per_layer": round(sel / a.steps / NUM_LAYERS * 1e3, 5),
+                               "note": "BASELINE config 4: one 32k sequence, %d heads per GPU; latency-bound tail" % Hl}}
+        del ssets
+        torch.cuda.empty_cache()
 
-        def gstep():
-            for layer in range(NUM_LAYERS):
-                q, k, v = gsets[layer % NSETS]
-                P.ops.compress(q, k[:, ::4], v[:, ::4], w, ks[layer], "maxpool", 7, kv_group=4)
-        gstep()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            gstep()
-        torch.cuda.synchronize()
-        ge = time.perf_counter() - t0
-        out["extras"] = {"gqa_dedup_tokens_per_s": round(B * S * a.steps / ge, 1),
-                         "gqa_dedup_us_per_layer": round(ge / a.steps / NUM_LAYERS * 1e6, 2),
-                         "note": "K/V = repeat_kv of 8 KV heads, kernels read 1 head per group (opt-in config.gqa_dedup); not the headline value"}
-        del gsets
-
+    if world == 1 and not a.no_extras:
+        out["grid"], north = grid_rows(P, N, dt, dev, S, H, rl, alg_bytes)
+        out["roofline_kernels"].update(north)
+        out["extras"] = gqa_extra(P, dt, dev, S, H, ks, a.steps)
+        out["gpu_eager_baseline"] = gpu_eager_baseline(dt, dev, S, H, cap)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sets[0], ks, w, cap, a)
+        sets = make_sets(1, Hl, S, dt, dev, 1234 + rank, 1)
+        out["cpu_baseline"] = cpu_baseline(sets[0], ks, W, cap, a)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def grid_rows(P, N, dt, dev, S, H, rl, alg_bytes):
+    """Single SnapKV update_kv calls at B in {1,8} x budget in {128,2048}: wall time per call (events around 10 calls) and
+    device time per kernel (events on the dispatches).  Returns (rows, {gather_cap2048_B1, gather_cap2048_B8})."""
+    rows, north = [], {}
+    for B in (1, 8):
+        sets = make_sets(B, H, S, dt, dev, 7 + B, 2 if B > 1 else 4)
+        for cap in (128, 2048):
+            k_sel = cap - W
+            for it in range(3):
+                q, k, v = sets[it % len(sets)]
+                P.ops.compress(q, k, v, W, k_sel, "maxpool", 7)
+            torch.cuda.synchronize()
+            iters = 10
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for it in range(iters):
+                q, k, v = sets[it % len(sets)]
+                P.ops.compress(q, k, v, W, k_sel, "maxpool", 7)
+            ev1.record()
+            torch.cuda.synchronize()
+            call_us = ev0.elapsed_time(ev1) / iters * 1e3
+            N.prof_enable(True)
+            N.prof_read(reset=True)
+            for it in range(iters):
+                q, k, v = sets[it % len(sets)]
+                P.ops.compress(q, k, v, W, k_sel, "maxpool", 7)
+            torch.cuda.synchronize()
+            prof = N.prof_read(reset=True)
+            N.prof_enable(False)
+            alg = alg_bytes(B, H, S, k_sel)
+            row = {"policy": "snapkv", "B": B, "budget": cap, "S": S, "update_kv_us": round(call_us, 2),
+                   "tokens_per_s": round(B * S / call_us * 1e6, 0),
+                   "call_effective_frac_of_8TBps": round(sum(alg.values()) / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            for name, by in alg.items():
+                r = rl(prof, name, by)
+                if r:
+                    row[name] = {"us": r["avg_us"], "GBps": r["achieved"], "frac": r["frac"], "alg_MB": round(by / 1e6, 2)}
+            rows.append(row)
+            if cap == 2048:
+                north["gather_cap2048_B%d" % B] = rl(prof, "gather", alg["gather"], "gather (SnapKV budget 2048, S=%d, B=%d)" % (S, B))
+        del sets
+        torch.cuda.empty_cache()
+    return rows, north
+
+
+def gqa_extra(P, dt, dev, S, H, ks, steps):
+    """Extra (not `value`): the headline workload when K/V are handed over BEFORE repeat_kv (8 KV heads, what the
+    transformers adapter does): the kernels read every KV head once per group."""
+    if H % 4:
+        return None
+    sets = []
+    for (q, k, v) in make_sets(1, H, S, dt, dev, 4321, 4):
+        sets.append((q, k[:, ::4].contiguous(), v[:, ::4].contiguous()))
+
+    def gstep():
+        for layer in range(NUM_LAYERS):
+            q, k, v = sets[layer % len(sets)]
+            P.ops.compress(q, k, v, W, ks[layer], "maxpool", 7, kv_group=4)
+    gstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gstep()
+    torch.cuda.synchronize()
+    ge = time.perf_counter() - t0
+    return {"unexpanded_gqa_tokens_per_s": round(S * steps / ge, 1),
+            "unexpanded_gqa_us_per_layer": round(ge / steps / NUM_LAYERS * 1e6, 2),
+            "note": "K/V handed over before repeat_kv (8 KV heads for 32 query heads); not the headline value"}
+
+
+def gpu_eager_baseline(dt, dev, S, H, cap):
+    """Same-chip comparator: the reference's eager op sequence - the oracle restatement of
+    pyramidkv_utils.py:306-347, ``tensor.topk`` as the reference calls it - executed by PyTorch-ROCm on this GPU on the
+    same shapes, device time from events on the current stream.  A reported baseline like `cpu_baseline`, never the
+    product path."""
+    from oracle import pkv_oracle as O
+    (q, k, v), = make_sets(1, H, S, dt, dev, 555, 1)
+    res = {}
+    for budget in (cap, 2048):
+        def call():
+            with contextlib.redirect_stdout(io.StringIO()):
+                return O.snapkv_update_kv(k, q, v, W, budget, 7, "maxpool", topk_mode="reference")
+        for _ in range(2):
+            call()
+        torch.cuda.synchronize()
+        iters = 5
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(iters):
+            call()
+        ev1.record()
+        torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) / iters * 1e3
+        res["snapkv_budget%d" % budget] = {"update_kv_us": round(us, 1), "tokens_per_s": round(S / us * 1e6, 0)}
+    res["kind"] = "reference op sequence (oracle restatement) on torch %s, device %s" % (torch.__version__, torch.cuda.get_device_name(dev))
+    res["workload"] = "[1,%d,%d,128] %s, window 8, maxpool7, one update_kv call" % (H, S, str(dt).replace("torch.", ""))
+    return res
 
 
 def cpu_baseline(qkv, ks, w, cap, a):
@@ -275,7 +404,11 @@ def cpu_baseline(qkv, ks, w, cap, a):
                 break
     except OSError:
         pass
+    gold = os.path.join(ROOT, "tests", "golden", "index.json")
+    nfix = len(json.load(open(gold)).get("cases", [])) if os.path.exists(gold) else 0
     return {"value": round(S * len(layers) / NUM_LAYERS / t, 1), "unit": "tokens/s", "cores": best_n, "kind": "port",
+            "port_checked_against": "oracle/pkv_oracle.py == the real reference (pyramidkv/pyramidkv_utils.py, imported) bit-for-bit on "
+                                    "%d committed fixtures (tests/golden/, tests/test_oracle_golden.py)" % nfix,
             "sample": "%d of the 32 layer-calls per pass (layers %s) of the same workload ([1,%d,%d,128] %s), %d passes = %.1f s "
                       "of CPU work, fastest pass %.2f s; host has %d logical CPUs, thread count picked by a 1-call probe"
                       % (len(layers), layers if len(layers) < NUM_LAYERS else "0..31", q.shape[1], S, a.dtype, passes, spent, t, ncpu),

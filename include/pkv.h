@@ -38,7 +38,8 @@ enum pkv_status {
   PKV_ERR_WORKSPACE = -4,   /* workspace too small */
   PKV_ERR_UNSUPPORTED = -5, /* valid request outside the limits of this build */
   PKV_ERR_HIP = -6,         /* a HIP runtime call failed; see pkv_last_hip_error() */
-  PKV_ERR_NULL = -7
+  PKV_ERR_NULL = -7,
+  PKV_ERR_COLLECTIVE = -8   /* an RCCL call failed; see pkv_last_nccl_error() */
 };
 
 enum pkv_dtype { PKV_BF16 = 0, PKV_F16 = 1 };
@@ -153,6 +154,19 @@ int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const vo
                             const void* state, const int32_t* head_lens, const int32_t* cu_klen,
                             void* out, pkv_stream_t stream);
 
+/* ---- multi-GPU: the one exchange step of the head-sharded path (the reference has no
+ * collective: run_longbench.py:390 only places layers with device_map="auto") ----
+ * Every rank holds idx_local int32 [B][H_local][k] (its heads, from pkv_compress); after the call every rank holds
+ * idx_all int32 [B][nranks*H_local][k] (heads in rank order).  ONE ncclAllGather on `stream`; for B > 1 plus one small
+ * regroup kernel (rank-major -> head-major), which needs ws >= nranks*B*H_local*k*4 bytes (ws may be NULL for B == 1).
+ * nccl_comm is the caller's ncclComm_t (libpkv creates none and does not link RCCL: the entry points are taken from the
+ * RCCL already loaded in the process - PyTorch's, or the one named by PKV_RCCL_LIB, else librccl.so.1).
+ * PyTorch does not expose its communicator, so the Python host issues the same collective through torch.distributed
+ * (pyramidkv_amd/dist.py); a C/C++ host calls this. */
+int pkv_allgather_indices(void* nccl_comm, const int32_t* idx_local, int32_t* idx_all, int32_t B, int32_t H_local,
+                          int32_t k, void* ws, size_t ws_bytes, pkv_stream_t stream);
+int pkv_last_nccl_error(void); /* ncclResult_t of the last PKV_ERR_COLLECTIVE on this thread */
+
 /* ---- per-kernel device timing (hipEvent pairs on `stream`), used by bench.py ---- */
 enum pkv_kernel_id {
   PKV_K_LOGITS = 0, PKV_K_FINALIZE = 1, PKV_K_TOPK = 2, PKV_K_GATHER = 3, PKV_K_H2O_STATS = 4,
@@ -161,7 +175,11 @@ enum pkv_kernel_id {
 int pkv_prof_enable(int on);                                   /* returns previous state */
 int pkv_prof_read(double* ms_sum, int64_t* launches, int reset); /* arrays of PKV_K_COUNT; syncs events */
 
-/* ---- debug / test hooks (not part of the drop-in surface) ---- */
+/* ---- debug / test hooks (not part of the drop-in surface) ----
+ * The trace hooks and the PKV_LOGITS_ABLATE measurement knob exist only in the -DPKV_DEBUG build (libpkv_debug.so,
+ * `make -C pyramidkv_amd/csrc debug`); the release library returns PKV_ERR_UNSUPPORTED for a non-NULL buffer and
+ * never reads the environment variable. */
+int pkv_debug_build(void);                    /* 1 = this library was built with -DPKV_DEBUG */
 int pkv_debug_topk_trace(void* device_u64x8); /* NULL disables; row 0 of every later top-k launch stamps 7 phase clocks */
 int pkv_debug_wg_trace(void* device_u64);     /* NULL disables; 2*262144 u64: per-workgroup (start,end) wall clock, 100 MHz */
 int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream); /* the kernels' exp(), for accuracy tests */

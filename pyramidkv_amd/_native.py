@@ -11,7 +11,8 @@ import os
 import torch  # imported first so that libamdhip64.so.7 resolves to the runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpkv.so")
+# PKV_LIB selects another build of the same ABI (tools/ load libpkv_debug.so, the -DPKV_DEBUG build with trace hooks)
+LIB_PATH = os.environ.get("PKV_LIB") or os.path.join(_HERE, "libpkv.so")
 
 PKV_BF16, PKV_F16 = 0, 1
 POOL = {None: 0, "none": 0, "avgpool": 1, "maxpool": 2}
@@ -62,6 +63,9 @@ def _load():
         "pkv_ada_metadata": (C.c_int, [i32, i32, vp, vp, vp, vp]),
         "pkv_gather_flat": (C.c_int, [dp, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
         "pkv_update_flatten_view": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "pkv_allgather_indices": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+        "pkv_last_nccl_error": (C.c_int, []),
+        "pkv_debug_build": (C.c_int, []),
         "pkv_debug_topk_trace": (C.c_int, [vp]),
         "pkv_debug_wg_trace": (C.c_int, [vp]),
         "pkv_debug_exp": (C.c_int, [vp, vp, i64, vp]),
@@ -85,6 +89,8 @@ def check(rc: int, what: str = "") -> None:
     msg = lib.pkv_strerror(rc).decode()
     if rc == -6:
         msg += f" (hipError {lib.pkv_last_hip_error()})"
+    if rc == -8:
+        msg += f" (ncclResult {lib.pkv_last_nccl_error()})"
     if rc in (-1, -2, -3, -5):
         raise ValueError(f"libpkv {what}: {msg}")
     raise PkvError(f"libpkv {what}: {msg}")

@@ -31,7 +31,15 @@ int logits_nt() { static int t = env_int("PKV_LOGITS_NT", 0); return t; }
 int logits_v2() { static int t = env_int("PKV_LOGITS_V2", 1); return t; }
 int logits_v2_nt() { static int t = env_int("PKV_LOGITS_NT", 1); return t; }
 int logits_v2_wgs() { static int t = env_int("PKV_LOGITS_V2_WGS", 0); return t; }   // target workgroup count, 0 = 8 per CU
-int logits_ablate() { static int t = env_int("PKV_LOGITS_ABLATE", 0); return t; }   // measurement only: wrong results
+#ifdef PKV_DEBUG
+int logits_ablate() { static int t = env_int("PKV_LOGITS_ABLATE", 0); return t; }   // measurement only: wrong results (debug build)
+#else
+constexpr int logits_ablate() { return 0; }   // the release library never reads PKV_LOGITS_ABLATE
+#endif
+
+// gather shape (both settings give identical results; defaults are the measured best, env vars exist for A/B runs)
+int gather_rpt() { static int t = env_int("PKV_GATHER_RPT", 4); return t; }
+int gather_xcd() { static int t = env_int("PKV_GATHER_XCD", 1); return t; }
 
 inline int hip_fail(hipError_t e) { g_last_hip = (int)e; return PKV_ERR_HIP; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -266,6 +274,7 @@ GatherParams make_gather(const pkv_desc* d, const void* k, const void* v, void* 
   GatherParams g;
   g.kptr = k; g.vptr = v; g.k_out = ko; g.v_out = vo;
   g.idx = nullptr; g.idx_stride = 0; g.head_k = nullptr; g.cu_rows = nullptr; g.wgtrace = g_wg_trace;
+  g.rpt = gather_rpt(); g.xcd_map = gather_xcd(); g.nblk = 0;
   g.B = d->B; g.H = d->H; g.S = d->S; g.w = d->window; g.nsel = d->topk; g.G = d->kv_group;
   g.ks_b = d->k_stride[0]; g.ks_h = d->k_stride[1]; g.ks_s = d->k_stride[2];
   g.vs_b = d->v_stride[0]; g.vs_h = d->v_stride[1]; g.vs_s = d->v_stride[2];
@@ -319,6 +328,7 @@ const char* pkv_strerror(int s) {
     case PKV_ERR_UNSUPPORTED: return "request outside the limits of this build";
     case PKV_ERR_HIP: return "HIP runtime error";
     case PKV_ERR_NULL: return "null pointer";
+    case PKV_ERR_COLLECTIVE: return "RCCL call failed";
     default: return "unknown status";
   }
 }
@@ -480,9 +490,15 @@ int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const vo
 }
 
 /* ---- debug / test hooks (not part of the drop-in surface) ---- */
+#ifdef PKV_DEBUG
 int pkv_debug_topk_trace(void* device_u64x8) { g_topk_trace = static_cast<unsigned long long*>(device_u64x8); return PKV_OK; }
-
 int pkv_debug_wg_trace(void* device_u64) { g_wg_trace = static_cast<unsigned long long*>(device_u64); return PKV_OK; }
+int pkv_debug_build(void) { return 1; }
+#else   // release library: the trace hooks do not exist in the kernels (see pkv_kernels.hpp)
+int pkv_debug_topk_trace(void* device_u64x8) { return device_u64x8 ? PKV_ERR_UNSUPPORTED : PKV_OK; }
+int pkv_debug_wg_trace(void* device_u64) { return device_u64 ? PKV_ERR_UNSUPPORTED : PKV_OK; }
+int pkv_debug_build(void) { return 0; }
+#endif
 
 int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream) {
   hipError_t e = launch_debug_exp(in, out, n, static_cast<hipStream_t>(stream));

@@ -13,77 +13,102 @@
 
 namespace pkv {
 
-constexpr int GA_ROWS = 64;   // output rows per workgroup (x2 tensors)
-
+// Work decomposition: one workgroup = 16*RPT output rows x {K,V} of one (b,h); RPT rows per lane and tensor
+// (RPT = 4 -> 64 rows, 8 independent 16-B loads per lane).  The grid is one-dimensional so that the block -> (head,
+// row block) map can follow the hardware's round-robin block -> XCD placement (block b runs on XCD b % 8, observed, used
+// for speed only): the indices of head bh were written by top-k workgroup bh, i.e. on XCD bh % 8, and the gather
+// blocks of that head are placed on the same XCD, where the index lines are still in the L2 - the one dependent
+// round trip before any row can move is then an L2 hit instead of a trip to the fabric.
+template <int RPT>
 __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
+  constexpr int ROWS = 16 * RPT;
   const int tid = threadIdx.x;
   const int chunk = tid & 15;          // 16-B chunk of the 256-B row
   const int slot = tid >> 4;           // 16 row slots
-  const int bh = blockIdx.y;
+  const int BH = p.B * p.H;
+  int bh, blk;
+  if (p.xcd_map) {                     // BH % 8 == 0 (host-checked)
+    const int id = blockIdx.x, x = id & 7, q = id >> 3, hpx = BH >> 3;
+    blk = q / hpx;
+    bh = (q - blk * hpx) * 8 + x;
+  } else {
+    bh = blockIdx.x / p.nblk;
+    blk = blockIdx.x - bh * p.nblk;
+  }
   const int b = bh / p.H;
   const int h = bh - b * p.H;
   const int hk = h / p.G;
   const int L = p.S - p.w;
   const int nsel = p.head_k ? p.head_k[bh] : p.nsel;
   const int nrows = nsel + p.w;
-  const int r_blk = blockIdx.x * GA_ROWS;
+  const int r_blk = blk * ROWS;
   if (r_blk >= nrows) return;
-  const unsigned long long t_start = p.wgtrace ? wall_clock64() : 0ull;
+  const unsigned long long t_start = PKV_WGTRACE(p) ? wall_clock64() : 0ull;
   const int64_t out_row0 = p.cu_rows ? (int64_t)p.cu_rows[bh] : (int64_t)bh * nrows;
 
   const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h + chunk * 8;
   const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.vptr) + (int64_t)b * p.vs_b + (int64_t)hk * p.vs_h + chunk * 8;
   const int32_t* ib = p.idx ? p.idx + (int64_t)bh * p.idx_stride : nullptr;
 
-  // All loads are unconditional (invalid slots read row 0 and are simply not stored) so that the four
-  // index loads and then the eight 16-B row loads are issued back to back: two dependent memory round
+  // All loads are unconditional (invalid slots read row 0 and are simply not stored) so that the RPT
+  // index loads and then the 2*RPT 16-B row loads are issued back to back: two dependent memory round
   // trips per workgroup instead of one per row.
-  int src[4];
-  bool ok[4];
-  int gi[4];
-  if (ib) {                                     // uniform branch; the four loads inside are unconditional
+  int src[RPT];
+  bool ok[RPT];
+  int gi[RPT];
+  if (ib) {                                     // uniform branch; the loads inside are unconditional
     const int last = nsel > 0 ? nsel - 1 : 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RPT; ++j) {
       const int r = r_blk + j * 16 + slot;
       gi[j] = __builtin_nontemporal_load(ib + (r < last ? r : last));
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gi[j] = r_blk + j * 16 + slot;
+    for (int j = 0; j < RPT; ++j) gi[j] = r_blk + j * 16 + slot;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < RPT; ++j) {
     const int r = r_blk + j * 16 + slot;
     ok[j] = r < nrows;
-    const int s = (r < nsel) ? gi[j] : L + (r - nsel);
+    // a selected index outside [0, L) (the reference's gather raises there) is clamped: never an out-of-bounds read
+    const int g = min(max(gi[j], 0), L - 1);
+    const int s = (r < nsel) ? g : L + (r - nsel);
     src[j] = ok[j] ? s : 0;
   }
-  u32x4 kd[4], vd[4];
+  u32x4 kd[RPT], vd[RPT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < RPT; ++j) {
     kd[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (int64_t)src[j] * p.ks_s));
     vd[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (int64_t)src[j] * p.vs_s));
   }
   uint16_t* ko = reinterpret_cast<uint16_t*>(p.k_out) + chunk * 8;
   uint16_t* vo = reinterpret_cast<uint16_t*>(p.v_out) + chunk * 8;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < RPT; ++j) {
     if (ok[j]) {
       const int64_t orow = out_row0 + r_blk + j * 16 + slot;
       __builtin_nontemporal_store(kd[j], reinterpret_cast<u32x4*>(ko + orow * 128));
       __builtin_nontemporal_store(vd[j], reinterpret_cast<u32x4*>(vo + orow * 128));
     }
   }
-  if (p.wgtrace && tid == 0) {
-    const size_t wg = 196608 + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (wg < 262144) { p.wgtrace[2 * wg] = t_start; p.wgtrace[2 * wg + 1] = wall_clock64(); }
+  if (PKV_WGTRACE(p) && tid == 0) {
+    const size_t wg = 196608 + (size_t)blockIdx.x;
+    if (wg < 262144) { PKV_WGTRACE(p)[2 * wg] = t_start; PKV_WGTRACE(p)[2 * wg + 1] = wall_clock64(); }
   }
 }
 
-hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st) {
-  dim3 grid((max_rows + GA_ROWS - 1) / GA_ROWS, p.B * p.H);
-  PKV_KLAUNCH(gather_kernel, grid, dim3(256), 0, st, p);
+hipError_t launch_gather(const GatherParams& p0, int max_rows, hipStream_t st) {
+  GatherParams p = p0;
+  const int rpt = p.rpt == 2 || p.rpt == 8 ? p.rpt : 4;
+  const int rows = 16 * rpt;
+  const int BH = p.B * p.H;
+  p.nblk = (max_rows + rows - 1) / rows;
+  if (BH % 8 != 0) p.xcd_map = 0;
+  dim3 grid((unsigned)(p.nblk * BH));
+  if (rpt == 2) PKV_KLAUNCH(gather_kernel<2>, grid, dim3(256), 0, st, p);
+  else if (rpt == 8) PKV_KLAUNCH(gather_kernel<8>, grid, dim3(256), 0, st, p);
+  else PKV_KLAUNCH(gather_kernel<4>, grid, dim3(256), 0, st, p);
   return hipGetLastError();
 }
 

@@ -21,6 +21,19 @@ extern thread_local KernelEvents* g_kev;
     }                                                                                                               \
   } while (0)
 
+// Measurement hooks (phase stamps, per-workgroup wall clocks, ablations that produce WRONG results) exist only in the
+// -DPKV_DEBUG build (make debug -> libpkv_debug.so, loaded by tools/ through PKV_LIB); in the release library the
+// accessors below are compile-time constants, so the hot loops carry no trace/ablation branches at all.
+#ifdef PKV_DEBUG
+#define PKV_ABLATE(p) ((p).ablate)
+#define PKV_WGTRACE(p) ((p).wgtrace)
+#define PKV_TRACE(p) ((p).trace)
+#else
+#define PKV_ABLATE(p) 0
+#define PKV_WGTRACE(p) (static_cast<unsigned long long*>(nullptr))
+#define PKV_TRACE(p) (static_cast<unsigned long long*>(nullptr))
+#endif
+
 struct LogitsParams {
   unsigned long long* wgtrace;   // debug: per-workgroup (start,end) wall clock, may be null
   const void* q;
@@ -92,6 +105,9 @@ struct GatherParams {
   int B, H, S, w, nsel, G;   // nsel = uniform selected-row count k
   int64_t ks_b, ks_h, ks_s;
   int64_t vs_b, vs_h, vs_s;
+  int rpt;                   // rows per lane and tensor: 2, 4 or 8 (16*rpt rows per workgroup)
+  int xcd_map;               // place the blocks of head bh on XCD bh % 8 (where top-k wrote its indices)
+  int nblk;                  // row blocks per head (set by launch_gather)
 };
 
 struct BudgetParams {

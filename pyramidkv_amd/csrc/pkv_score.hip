@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   const int S = p.S;
   const int L = S - w;
 
-  const unsigned long long t_start = p.wgtrace ? wall_clock64() : 0ull;
+  const unsigned long long t_start = PKV_WGTRACE(p) ? wall_clock64() : 0ull;
   const int li = lane & 15;   // key within 16-subtile (A rows) / column within 16-tile (B cols)
   const int lg = lane >> 4;   // 8-element d-chunk within a 32-wide k-step
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
     }
   }
 
-  if (p.ablate == 3) {   // measurement aid: K loads only
+  if (PKV_ABLATE(p) == 3) {   // measurement aid: K loads only
     u32x4 a = {0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < NSUB; ++t)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(kf[t][kk], qf[kk], acc);
-      if (p.ablate == 2) {   // measurement aid: loads + MFMA only
+      if (PKV_ABLATE(p) == 2) {   // measurement aid: loads + MFMA only
         if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e30f) p.partial[0] = make_float2(0.f, 0.f);
         continue;
       }
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
       if (c < C) *reinterpret_cast<uint2*>(tile + c * LROW + key0) = make_uint2(p01, p23);
     }
   }
-  if (p.ablate >= 1) return;   // measurement aid: no statistics / logits store
+  if (PKV_ABLATE(p) >= 1) return;   // measurement aid: no statistics / logits store
   __syncthreads();
 
   // ---- per-row tile statistics + coalesced 16-B store of the logits tile (CH lanes per row) ----
@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
     if (chunk == 0) p.partial[(rowbase + row) * p.nT + t_idx] = make_float2(m, l);
     *reinterpret_cast<uint4*>(lg_out + (rowbase + row) * (int64_t)p.Sp + s0) = u.v;
   }
-  if (p.wgtrace && tid == 0) {
+  if (PKV_WGTRACE(p) && tid == 0) {
     const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    p.wgtrace[2 * wg] = t_start; p.wgtrace[2 * wg + 1] = wall_clock64();
+    PKV_WGTRACE(p)[2 * wg] = t_start; PKV_WGTRACE(p)[2 * wg + 1] = wall_clock64();
   }
 }
 
@@ -204,9 +204,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   const int w = p.w;
   const int L = p.S - w;
   const int64_t rowbase = (int64_t)bh * w;
-#define PKV_FSTAMP(i) do { if (p.trace && tid == 0 && blockIdx.x == 1 && bh == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
+#define PKV_FSTAMP(i) do { if (PKV_TRACE(p) && tid == 0 && blockIdx.x == 1 && bh == 0) PKV_TRACE(p)[i] = (unsigned long long)clock64(); } while (0)
   PKV_FSTAMP(0);
-  const unsigned long long t_start = p.wgtrace ? wall_clock64() : 0ull;
+  const unsigned long long t_start = PKV_WGTRACE(p) ? wall_clock64() : 0ull;
 
   // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M).
   // 32 lanes per row, 8 rows per pass; every lane issues its (<= 8 per chunk) partial loads back to
@@ -305,9 +305,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   __syncthreads();
   PKV_FSTAMP(3);
 
-  if (p.wgtrace && tid == 0) {
+  if (PKV_WGTRACE(p) && tid == 0) {
     const size_t wg = 65536 + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    p.wgtrace[2 * wg] = t_start; p.wgtrace[2 * wg + 1] = wall_clock64();
+    PKV_WGTRACE(p)[2 * wg] = t_start; PKV_WGTRACE(p)[2 * wg + 1] = wall_clock64();
   }
   const bool writer = !(tid < 2 || tid >= 254 || s0 >= L);   // halo threads / positions past the row write nothing
   uint16_t res[4];
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   ro.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
   uint16_t* out = reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride + s0;
   *reinterpret_cast<uint2*>(out) = ro;      // stride % 8 == 0, s0 % 4 == 0, stride >= roundup(L,8): aligned, in bounds
-  if (p.trace && tid == 2 && blockIdx.x == 1 && bh == 0) p.trace[4] = (unsigned long long)clock64();
+  if (PKV_TRACE(p) && tid == 2 && blockIdx.x == 1 && bh == 0) PKV_TRACE(p)[4] = (unsigned long long)clock64();
 #undef PKV_FSTAMP
 }
 
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void logits2_kernel(LogitsParams p) {
 #pragma unroll
       for (int i = 1; i < 8; ++i) m_loc = fmaxf(m_loc, xs[i]);
       const float m_new = fmaxf(m_run[n], m_loc);
-      if (p.ablate == 2) { m_run[n] = m_new; continue; }   // measurement aid: no exponentials
+      if (PKV_ABLATE(p) == 2) { m_run[n] = m_new; continue; }   // measurement aid: no exponentials
       const float ms = (m_new == -INFINITY) ? 0.f : m_new;
       float sum = 0.f;
 #pragma unroll
@@ -521,14 +521,14 @@ __global__ __launch_bounds__(256) void logits2_kernel(LogitsParams p) {
       l_run[n] = l_run[n] * pkv_exp(m_run[n] - ms) + sum;
       m_run[n] = m_new;
     }
-    if (p.ablate == 1 || p.ablate == 2) continue;        // measurement aid: no logits store
+    if (PKV_ABLATE(p) == 1 || PKV_ABLATE(p) == 2) continue;        // measurement aid: no logits store
     __syncthreads();
-    if (p.ablate == 4) continue;        // measurement aid: barrier only
+    if (PKV_ABLATE(p) == 4) continue;        // measurement aid: barrier only
     // logits of the stage: C rows x 256 B, 16 B per item
     for (int it = tid; it < C * 16; it += 256) {
       const int row = it >> 4, ch = it & 15;
       const uint4 v = *reinterpret_cast<const uint4*>(tile + row * LROW + ch * 8);
-      if (p.ablate == 3) {              // measurement aid: the same stores into a per-workgroup 2 KB patch that stays in L2
+      if (PKV_ABLATE(p) == 3) {              // measurement aid: the same stores into a per-workgroup 2 KB patch that stays in L2
         *reinterpret_cast<uint4*>(lg_out + ((int64_t)((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 128 + it) * 8) = v;
         continue;
       }

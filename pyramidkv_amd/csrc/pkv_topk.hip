@@ -178,9 +178,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   const int cslot = lane & 31;
   const int niter = Lw / 512;
 
-#define PKV_STAMP(i) do { if (p.trace && tid == 0 && row == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
+#define PKV_STAMP(i) do { if (PKV_TRACE(p) && tid == 0 && row == 0) PKV_TRACE(p)[i] = (unsigned long long)clock64(); } while (0)
   PKV_STAMP(0);
-  const unsigned long long t_start = p.wgtrace ? wall_clock64() : 0ull;
+  const unsigned long long t_start = PKV_WGTRACE(p) ? wall_clock64() : 0ull;
   // ---- pass A: HBM/L2 -> ordered keys in LDS, histogram of the high byte.  All (<= 8) 16-B loads of a
   //      lane are issued first; the counter arrays are zeroed while they are in flight. ----
   const int nch = (L + 7) >> 3;                                   // 8-key chunks in the row
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   load_all();
   for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
   __syncthreads();
-  if (p.trace && tid == 0 && row == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[7] = (unsigned long long)clock64(); }
+  if (PKV_TRACE(p) && tid == 0 && row == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PKV_TRACE(p)[7] = (unsigned long long)clock64(); }
   U4 kreg[8];     // this lane's ordered keys (niter chunks of 8), kept in registers for every later pass
   auto transform_all = [&]() {
 #pragma unroll
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
 #pragma unroll
     for (int w2 = 0; w2 < TK_WAVES; ++w2) { const uint32_t c = wcnt[w2]; C += c; cbase += (w2 < wave) ? c : 0u; }
     PKV_STAMP(3);
-    if (p.trace && tid == 0 && row == 0) p.trace[15] = C;
+    if (PKV_TRACE(p) && tid == 0 && row == 0) PKV_TRACE(p)[15] = C;
     // rank = number of list entries with a larger composite; entries with rank < k are the selection and
     // the rank is the output position.  All 1024 threads take part: an entry is shared by G <= 4 adjacent
     // lanes, each scanning every G-th block of 32 composites (8 independent 16-B broadcast reads per step).
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
           p.idx_out[(int64_t)vrow * p.idx_stride + i] = seg_off + (int32_t)(0xffffu - (cand[i] & 0xffffu));
       }
       PKV_STAMP(6);
-      if (p.wgtrace && tid == 0) { p.wgtrace[2 * (131072 + row)] = t_start; p.wgtrace[2 * (131072 + row) + 1] = wall_clock64(); }
+      if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
       return;
     }
     // too many keys at or above x* (heavy ties): full path.  Its counters must start from zero.
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     for (int i = tid; i < k; i += TK_THREADS) out[i] = seg_off + (int32_t)(0xffffu - (sel[i] & 0xffffu));
   }
   PKV_STAMP(6);
-  if (p.wgtrace && tid == 0) { p.wgtrace[2 * (131072 + row)] = t_start; p.wgtrace[2 * (131072 + row) + 1] = wall_clock64(); }
+  if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
 #undef PKV_STAMP
 }
 
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
   uint16_t* ov = p.sorted_val ? reinterpret_cast<uint16_t*>(p.sorted_val) + (int64_t)row * L : nullptr;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-#define PKV_SSTAMP(i) do { if (p.trace && tid == 0 && row == 0) p.trace[i] = (unsigned long long)clock64(); } while (0)
+#define PKV_SSTAMP(i) do { if (PKV_TRACE(p) && tid == 0 && row == 0) PKV_TRACE(p)[i] = (unsigned long long)clock64(); } while (0)
   PKV_SSTAMP(0);
   for (int i = tid; i < L; i += TK_THREADS) val[i] = src[i];
   __syncthreads();

@@ -24,11 +24,11 @@ def shard_heads(num_heads: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
-def allgather_indices(idx_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+def allgather_indices(idx_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None, force: bool = False) -> torch.Tensor:
     """idx_local int32 [B, H/N, k] on every rank -> int32 [B, H, k] on every rank (head-major order =
-    rank order).  One collective."""
+    rank order).  One collective.  ``force`` issues it even at world size 1 (RCCL smoke with nranks = 1)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return idx_local
     B, Hl, k = idx_local.shape
     out = torch.empty(world * B, Hl, k, dtype=idx_local.dtype, device=idx_local.device)   # rank-major concat
@@ -51,13 +51,14 @@ class PendingIndices:
         return self._out.view(world, B, Hl, k).permute(1, 0, 2, 3).reshape(B, world * Hl, k)
 
 
-def allgather_indices_async(idx_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> PendingIndices:
+def allgather_indices_async(idx_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
+                            force: bool = False) -> PendingIndices:
     """Same exchange as ``allgather_indices`` but not waited for: the next layer's update_kv does not depend on this
     layer's gathered indices, so the KB-sized, latency-bound collective overlaps with it (RCCL runs it on its own
     stream).  Call ``.wait()`` before the indices are consumed."""
     world = dist.get_world_size(group)
     B, Hl, k = idx_local.shape
-    if world == 1:
+    if world == 1 and not force:
         return PendingIndices(idx_local.contiguous(), None, (1, B, Hl, k))
     out = torch.empty(world * B, Hl, k, dtype=idx_local.dtype, device=idx_local.device)
     work = dist.all_gather_into_tensor(out, idx_local.contiguous(), group=group, async_op=True)
