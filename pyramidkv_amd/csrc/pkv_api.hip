@@ -37,9 +37,11 @@ int logits_ablate() { static int t = env_int("PKV_LOGITS_ABLATE", 0); return t; 
 constexpr int logits_ablate() { return 0; }   // the release library never reads PKV_LOGITS_ABLATE
 #endif
 
+// small-k selection algorithm of topk_kernel (identical results): 1 = one-level histogram + bucket counting sort
+int topk_algo() { static int t = env_int("PKV_TOPK_ALGO", 1); return t; }
 // gather shape (both settings give identical results; defaults are the measured best, env vars exist for A/B runs)
-int gather_rpt() { static int t = env_int("PKV_GATHER_RPT", 4); return t; }
-int gather_xcd() { static int t = env_int("PKV_GATHER_XCD", 1); return t; }
+int gather_rpt() { static int t = env_int("PKV_GATHER_RPT", 0); return t; }   // 0 = by size (launch_gather)
+int gather_xcd() { static int t = env_int("PKV_GATHER_XCD", 0); return t; }
 
 inline int hip_fail(hipError_t e) { g_last_hip = (int)e; return PKV_ERR_HIP; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -236,7 +238,7 @@ int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t strid
   TopkParams tp;
   tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
   tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace; tp.wgtrace = g_wg_trace; tp.cmax = cmax; tp.cmax_stride = cmax_stride;
-  tp.nseg = 1; tp.seg_len = 0;
+  tp.nseg = 1; tp.seg_len = 0; tp.algo = topk_algo();
   auto launch = [&](int nrows, int Lwg) -> int {     // Lwg = keys one workgroup handles
     const size_t lds = topk_lds_bytes(Lwg, tp.k, &tp.Lw, &tp.kpad);
     if (lds > 160 * 1024 || 16 * (size_t)tp.Lw > 65536) return PKV_ERR_UNSUPPORTED;

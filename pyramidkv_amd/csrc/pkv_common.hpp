@@ -64,6 +64,11 @@ template <typename T> struct KeyBias;
 template <> struct KeyBias<BF16> { static constexpr uint32_t v = 0x007eu; };   // +inf 0xff80 -> 0xfffe
 template <> struct KeyBias<F16> { static constexpr uint32_t v = 0x03feu; };    // +inf 0xfc00 -> 0xfffe
 
+// key buckets of the small-k counting sort: bf16 has 128 keys per binade (one key per bucket), fp16 1024 (8 per bucket)
+template <typename T> struct KeyShift;
+template <> struct KeyShift<BF16> { typedef char tag; };
+template <> struct KeyShift<F16> { typedef short tag; };
+
 template <typename T> __device__ __forceinline__ uint32_t order_key(uint16_t h) {
   uint32_t k = (uint32_t)h ^ ((h & 0x8000u) ? 0xffffu : 0x8000u);
   if (k == 0x7fffu) k = 0x8000u;                      // -0 == +0

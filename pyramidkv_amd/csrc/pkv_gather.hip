@@ -100,13 +100,17 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
 
 hipError_t launch_gather(const GatherParams& p0, int max_rows, hipStream_t st) {
   GatherParams p = p0;
-  const int rpt = p.rpt == 2 || p.rpt == 8 ? p.rpt : 4;
+  // rows per lane: budgets of ~1000+ rows per head stream best with 8 (16 loads in flight per lane: 13.8 us against 14.6 us for
+  // 67 MB at B = 1), small budgets are launch-latency-bound and finish earlier with many small workgroups (measured, profiles/)
+  int rpt = p.rpt;
+  if (rpt != 2 && rpt != 4 && rpt != 8 && rpt != 16) rpt = max_rows >= 1024 ? 8 : 2;
   const int rows = 16 * rpt;
   const int BH = p.B * p.H;
   p.nblk = (max_rows + rows - 1) / rows;
   if (BH % 8 != 0) p.xcd_map = 0;
   dim3 grid((unsigned)(p.nblk * BH));
   if (rpt == 2) PKV_KLAUNCH(gather_kernel<2>, grid, dim3(256), 0, st, p);
+  else if (rpt == 16) PKV_KLAUNCH(gather_kernel<16>, grid, dim3(256), 0, st, p);
   else if (rpt == 8) PKV_KLAUNCH(gather_kernel<8>, grid, dim3(256), 0, st, p);
   else PKV_KLAUNCH(gather_kernel<4>, grid, dim3(256), 0, st, p);
   return hipGetLastError();

@@ -79,6 +79,7 @@ struct TopkParams {
   int Lw;                // keys per wave (multiple of 512)
   int kpad;              // words reserved for the selection list (see topk_lds_bytes)
   int dual;              // second 32 KB counter / radix scratch region present in LDS
+  int algo;              // small-k fast path: 1 = one-level histogram + bucket counting sort, 0 = two-level select + radix ordering
   int nseg, seg_len;     // long rows: workgroup r handles segment r % nseg (seg_len keys) of row r / nseg and writes
                          // row-global indices to idx_out row r; L stays the full row length.  nseg <= 1: off
 };

@@ -25,6 +25,10 @@ constexpr int TK_FAST_K = 512;           // k <= this: try the chunk-maxima pref
 constexpr int TK_FAST_C = 448;           // at most this many candidates: rank them directly (O(C^2)); above, the exact select inside the list is cheaper (measured crossover ~440)
 constexpr int TK_MID_C = 4096;           // at most this many: exact select inside the candidate list first
 constexpr size_t TK_LDS_LIMIT = 160 * 1024;
+// one-level fast path (algo 1): 13-bit histogram of the chunk maxima, passing chunks staged in LDS, bucket counting sort
+constexpr int TK2_PMAX = 2048;           // staged chunks (16 key slots per thread)
+constexpr int TK2_CMAX = 4096;           // candidates
+constexpr int TK2_NB = 2048;             // key buckets of the counting sort
 
 // LDS layout: keys u16[16*Lw] | X u32[max(8192,kpad)] | hist u32[256] | misc u32[64] | X2 u32[8192] (if it fits)
 size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out) {
@@ -243,7 +247,186 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       }
     }
   };
-  if (!use_cmax) transform_all();
+  const bool fast2 = fast_ok && dual && vec_ok && p.algo == 1;      // one-level fast path, see below
+  if (!use_cmax && !fast2) transform_all();
+
+  // ---- one-level fast path (algo 1, small k).  Cost model: 1024 threads on one CU = every wave-instruction costs
+  //      ~16 cycles of wall time, so nothing here touches all 32 keys of a lane.
+  //      (1) 13-bit histogram of the chunk maxima (4 per lane at S = 32k) -> x* = lower edge of the bin in which the
+  //          count of chunk maxima from the top reaches k: at least k keys are >= x*, so the top-k are among the keys >= x*;
+  //      (2) the chunks whose maximum reaches x* (about k of 4096) are staged in LDS by their owners; all threads then
+  //          look at the 8 keys of each staged chunk (dense), candidates (key >= x*) stay in registers as composites
+  //          key<<16 | (0xffff - index) and are counted per key bucket;
+  //      (3) counting sort by bucket (descending key), then every candidate ranks itself inside its bucket by comparing
+  //          composites: rank == output position, rank < k == selected.  Canonical order (value desc, index asc) by
+  //          construction.  Heavy ties (too many staged chunks / candidates) fall through to the exact full path. ----
+  if (fast2) {
+    uint32_t* H13 = X;                                        // [8192], zeroed above
+    uint32_t* HB = X2;                                        // [2048] bucket counters, zeroed above
+    uint32_t* tmpl = X2 + TK2_NB;                             // [4096] candidates in bucket order
+    uint4* stage_raw = reinterpret_cast<uint4*>(smem);        // [pmax] raw 16-B chunks (the `keys` region is unused here)
+    const int pmax = Lw < TK2_PMAX ? Lw : TK2_PMAX;           // 18 * pmax <= 32 * Lw bytes
+    uint16_t* stage_id = reinterpret_cast<uint16_t*>(smem + (size_t)16 * pmax);
+    uint32_t gm[8];
+    if (tid == 0) miscu[4] = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < niter) {
+        const int c = wave * (Lw >> 3) + j * 64 + lane;
+        uint32_t m = 0;
+        if (use_cmax) {
+          m = order_key<T>(cm[j]);
+        } else {
+          const int base = wave * Lw + j * 512 + lane * 8;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t kk = order_key_pk<T>(raw[j].w[q]);
+            const uint32_t lo = (base + 2 * q < L) ? (kk & 0xffffu) : 0u, hi = (base + 2 * q + 1 < L) ? (kk >> 16) : 0u;
+            m = m > lo ? m : lo;
+            m = m > hi ? m : hi;
+          }
+        }
+        gm[j] = c < nch ? m : 0u;
+        if (c < nch) atomicAdd(&H13[m >> 3], 1u);
+      }
+    }
+    __syncthreads();
+    // bin b* with  above(b*) < k <= above(b*) + H13[b*]  (above = count in higher bins).  A lane owns bins 8*tid .. 8*tid+7,
+    // four lanes a coarse bin of 32; the 256 coarse sums go to `hist`, and every wave then finds the coarse bin and, inside
+    // it, the fine bin on its own (no LDS hand-off of the result, no third barrier).
+    uint32_t xstar;
+    {
+      const uint4 h0 = reinterpret_cast<const uint4*>(H13)[2 * tid], h1 = reinterpret_cast<const uint4*>(H13)[2 * tid + 1];
+      uint32_t s8 = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
+      s8 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s8, 0xb1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+      s8 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s8, 0x4e, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+      if ((tid & 3) == 0) hist[tid >> 2] = s8;
+      __syncthreads();
+      const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];
+      const uint32_t hv[4] = {h.x, h.y, h.z, h.w};
+      const uint32_t own = h.x + h.y + h.z + h.w;
+      const uint32_t incl = wave_incl_scan_u32(own);
+      uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl;     // count in the bins of higher lanes
+      uint32_t cb = 0, cab = 0;
+      bool hit = false;
+#pragma unroll
+      for (int i = 3; i >= 0; --i) {
+        if (above < (uint32_t)k && (uint32_t)k <= above + hv[i]) { hit = true; cb = (uint32_t)(lane * 4 + i); cab = above; }
+        above += hv[i];
+      }
+      const int src = __builtin_ctzll(__ballot(hit));                                    // exactly one lane hits (nch >= k chunks)
+      cb = (uint32_t)__builtin_amdgcn_readlane((int)cb, src);
+      cab = (uint32_t)__builtin_amdgcn_readlane((int)cab, src);
+      const uint32_t cf = lane < 32 ? H13[cb * 32 + lane] : 0u;
+      const uint32_t incl2 = wave_incl_scan_u32(cf);
+      const uint32_t above2 = cab + (uint32_t)__builtin_amdgcn_readlane((int)incl2, 63) - incl2;
+      const bool hit2 = above2 < (uint32_t)k && (uint32_t)k <= above2 + cf;
+      const int src2 = __builtin_ctzll(__ballot(hit2));
+      xstar = (cb * 32 + (uint32_t)src2) << 3;
+    }
+    PKV_STAMP(1);
+    // stage the passing chunks: one LDS atomic per wave reserves the slots of all its passing chunks
+    {
+      // (the pass masks are recomputed in the second loop instead of being kept: 8 live 64-bit masks push this kernel over
+      // its scalar-register budget and every one of them then travels through v_writelane / v_readlane)
+      uint32_t npass = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < niter) npass += (uint32_t)__popcll(__ballot(gm[j] != 0u && gm[j] >= xstar));
+      uint32_t slot0 = 0;
+      if (lane == 0 && npass) slot0 = atomicAdd(&miscu[4], npass);
+      slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+      PKV_STAMP(4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < niter) {
+          const bool pass = gm[j] != 0u && gm[j] >= xstar;
+          const uint64_t mk = __ballot(pass);
+          if (mk != 0ull) {
+            const int c = wave * (Lw >> 3) + j * 64 + lane;
+            const uint32_t q = slot0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (pass && q < (uint32_t)pmax) { stage_raw[q] = raw[j].v; stage_id[q] = (uint16_t)c; }
+            slot0 += (uint32_t)__popcll(mk);
+          }
+        }
+      }
+      PKV_STAMP(13);
+    }
+    __syncthreads();
+    PKV_STAMP(2);
+    const uint32_t P = miscu[4];
+    bool ok2 = P <= (uint32_t)pmax;
+    if (ok2) {
+      // dense look at the 8 keys of every staged chunk; candidates stay in registers
+      constexpr int SH = sizeof(typename KeyShift<T>::tag) == 1 ? 0 : 3;          // bf16: one key per bucket; fp16: 8
+      const uint16_t* stage_h = reinterpret_cast<const uint16_t*>(stage_raw);
+      const int nslots = (int)P * 8;
+      const int ni = (nslots + TK_THREADS - 1) / TK_THREADS;          // workgroup-uniform trip count (<= 16)
+      uint32_t comp[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        comp[i] = 0u;
+        const int sl = tid + i * TK_THREADS;
+        if (i < ni && sl < nslots) {
+          const uint32_t key = order_key<T>(stage_h[sl]);
+          const uint32_t idx = (uint32_t)stage_id[sl >> 3] * 8u + (uint32_t)(sl & 7);
+          if ((int)idx < L && key >= xstar) {
+            comp[i] = (key << 16) | (0xffffu - idx);
+            const uint32_t db = (key - xstar) >> SH;
+            atomicAdd(&HB[TK2_NB - 1 - (db < (uint32_t)TK2_NB - 1 ? db : (uint32_t)TK2_NB - 1)], 1u);
+          }
+        }
+      }
+      __syncthreads();
+      // exclusive prefix over the 2048 buckets (ascending bucket = descending key); lane owns buckets 2*tid, 2*tid+1
+      const uint2 hb = reinterpret_cast<const uint2*>(HB)[tid];
+      const uint32_t own = hb.x + hb.y;
+      const uint32_t incl = wave_incl_scan_u32(own);
+      if (lane == 63) wcnt[16 + wave] = incl;
+      __syncthreads();
+      // cross-wave offsets: lane w reads the total of wave w, one wave scan gives every wave its base and the grand total
+      const uint32_t wt = lane < TK_WAVES ? wcnt[16 + lane] : 0u;
+      const uint32_t wincl = wave_incl_scan_u32(wt);
+      const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)wincl, 63);
+      const uint32_t lower = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wave);
+      if (PKV_TRACE(p) && tid == 0 && row == 0) PKV_TRACE(p)[15] = C;
+      ok2 = C <= (uint32_t)TK2_CMAX && C >= (uint32_t)k;
+      if (ok2) {
+        const uint32_t bs = lower + incl - own;
+        reinterpret_cast<uint2*>(HB)[tid] = make_uint2(bs, bs + hb.x);
+        __syncthreads();
+        PKV_STAMP(3);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i < ni && comp[i] != 0u) {
+            const uint32_t db = ((comp[i] >> 16) - xstar) >> SH;
+            const uint32_t dst = atomicAdd(&HB[TK2_NB - 1 - (db < (uint32_t)TK2_NB - 1 ? db : (uint32_t)TK2_NB - 1)], 1u);
+            tmpl[dst] = comp[i];
+          }
+        }
+        __syncthreads();
+        PKV_STAMP(5);
+        // HB[d] is now the END of bucket d; rank inside the bucket by comparing composites (unique)
+        for (int i = tid; i < (int)C; i += TK_THREADS) {
+          const uint32_t mine = tmpl[i];
+          const uint32_t db = ((mine >> 16) - xstar) >> SH;
+          const uint32_t d = TK2_NB - 1 - (db < (uint32_t)TK2_NB - 1 ? db : (uint32_t)TK2_NB - 1);
+          const uint32_t st = d ? HB[d - 1] : 0u, en = HB[d];
+          uint32_t rank = st;
+          for (uint32_t jj = st; jj < en; ++jj) rank += tmpl[jj] > mine;
+          if (rank < (uint32_t)k) p.idx_out[(int64_t)vrow * p.idx_stride + rank] = seg_off + (int32_t)(0xffffu - (mine & 0xffffu));
+        }
+        PKV_STAMP(6);
+        if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
+        return;
+      }
+    }
+    // heavy ties: exact full path.  Its key table and counters start from scratch.
+    __syncthreads();
+    transform_all();
+    for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; X2[i] = 0; }
+    __syncthreads();
+  }
 
   // ---- fast path (small k): the k-th largest of the per-chunk maxima is a lower bound x* of the
   //      selection threshold (at least k keys are >= x*), and usually only a few hundred keys pass it.
@@ -251,7 +434,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   //      key), compact the candidates in index order, and rank them by counting: rank < k <=> selected,
   //      and the rank IS the output position.  Falls back to the full radix select when too many
   //      keys tie at or above x*. ----
-  if (fast_ok) {
+  if (fast_ok && !fast2) {
     uint32_t gm[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -49,6 +49,43 @@ def _repeat_kv(x: torch.Tensor, n_rep: int) -> torch.Tensor:
     return x[:, :, None, :, :].expand(b, h, n_rep, s, d).reshape(b, h * n_rep, s, d)
 
 
+def _unslide_layer(cache, layer_idx: int) -> None:
+    """The reference runs on transformers 4.44.2, whose DynamicCache never crops.  transformers 5 gives models with a
+    ``sliding_window`` (Mistral-7B-v0.1) ``DynamicSlidingWindowLayer`` entries, which silently keep only the LAST
+    sliding_window - 1 rows on update - and the compacted cache stores its top-scored rows FIRST, so the crop would evict
+    the highest-scored tokens.  A compacted layer is therefore held in a plain ``DynamicLayer`` (as in the reference the
+    window limit then lives in the attention mask only)."""
+    layers = getattr(cache, "layers", None)
+    if layers is None:
+        return
+    from transformers.cache_utils import DynamicLayer
+    if getattr(cache, "layer_class_to_replicate", None) is not None and cache.layer_class_to_replicate is not DynamicLayer \
+            and getattr(cache.layer_class_to_replicate, "is_sliding", False):
+        cache.layer_class_to_replicate = DynamicLayer
+    if layer_idx < len(layers) and getattr(layers[layer_idx], "is_sliding", False):
+        layers[layer_idx] = DynamicLayer()
+
+
+def _track_tokens(cache, layer_idx: int, n_new: int, prefill: bool) -> None:
+    """True sequence length next to the compacted cache (the reference keeps ``self.kv_seq_len`` on the attention module,
+    llama_model.py:139-145,166,170,172).  After compaction the stock cache reports the COMPRESSED length, and a decode
+    loop that does not pass positions explicitly would derive RoPE positions from it (prompt ends at 149, next token
+    rotated as 48).  The cache instance gets a ``get_seq_length`` that reports the tokens seen so far for a layer that
+    holds content (0 for an empty layer, which is how the forward recognises the prefill call); mask sizes still come
+    from the layers, i.e. from the compacted length."""
+    if not hasattr(cache, "_pkv_seen_tokens"):
+        import types
+        inner = cache.get_seq_length
+        cache._pkv_seen_tokens = 0
+
+        def get_seq_length(self, layer_idx=0):
+            return 0 if inner(layer_idx) == 0 else self._pkv_seen_tokens
+
+        cache.get_seq_length = types.MethodType(get_seq_length, cache)
+    if layer_idx == 0:
+        cache._pkv_seen_tokens = n_new if prefill else cache._pkv_seen_tokens + n_new
+
+
 def _attend(module, q, k, v, attention_mask, is_prefill):
     """Attention over K/V with H heads (no second repeat_kv) or H/g heads (un-expanded: SDPA's grouped-query
     path, expanded views for eager).  eager = the reference's matmul / fp32 softmax / matmul
@@ -101,11 +138,14 @@ def _make_forward(method: str, apply_rotary_pos_emb: Callable):
                     k = _repeat_kv(k, self.num_key_value_groups)          # llama_model.py:158
                     v = _repeat_kv(v, self.num_key_value_groups)          # llama_model.py:159
                 kc, vc = self.kv_cluster.update_kv(k, q, v, attention_mask, self.num_key_value_groups)   # :167
+                _unslide_layer(past_key_values, self.layer_idx)
                 past_key_values.update(kc, vc, self.layer_idx)            # :168 (the prompt attends to the full K/V)
+                _track_tokens(past_key_values, self.layer_idx, q.shape[-2], True)     # kv_seq_len, :166
             else:
                 k = _repeat_kv(k, self.num_key_value_groups)              # one token: the cache holds all H heads
                 v = _repeat_kv(v, self.num_key_value_groups)
                 k, v = past_key_values.update(k, v, self.layer_idx)       # :171
+                _track_tokens(past_key_values, self.layer_idx, q.shape[-2], False)    # kv_seq_len += q_len, :172
         attn = _attend(self, q, k, v, attention_mask, is_prefill)
         attn = attn.reshape(*input_shape, -1).contiguous()
         return self.o_proj(attn), None

@@ -13,6 +13,7 @@ import torch
 from . import _native as N
 
 _WS: Dict[Tuple[int, int], torch.Tensor] = {}
+_WS_RETIRED: list = []      # superseded workspaces stay alive: a HIP graph captured earlier has their address baked in
 
 
 def _require_gpu(*ts):
@@ -30,11 +31,17 @@ def _rowmajor(t: torch.Tensor) -> torch.Tensor:
 
 
 def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    """Scratch per (device, stream), grown geometrically and NEVER freed or shrunk: the buffer a larger request
+    supersedes is kept alive (``_WS_RETIRED``), because a HIP graph captured while it was current replays with its
+    address.  Capture a graph only after one eager call of the same shape on the same stream (the workspace then exists
+    outside the graph's private pool); see INTEGRATION.md."""
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if ws is not None:
+            _WS_RETIRED.append(ws)
+        ws = torch.empty(max(nbytes, 2 * ws.numel() if ws is not None else 0, 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = ws
     return ws
 

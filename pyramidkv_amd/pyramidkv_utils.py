@@ -18,6 +18,7 @@ import torch
 
 from . import ops
 from . import config as _cfg
+from .cache import DynamicCacheSplitHeadFlatten  # noqa: F401  (llama_model.py:20 / mistral_model.py:20 import it from here)
 
 
 def _check_merge(merge):
@@ -428,6 +429,28 @@ def init_headkv(self):
             window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
             kernel_size=self.config.kernel_size, pooling=self.config.pooling,
             head_capacity=self.config.head_capacity)
+
+
+def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:
+    """reference pyramidkv_utils.py:108-117 (same name and behaviour: n_rep == 1 returns the input object)."""
+    return _repeat_kv(hidden_states, n_rep)
+
+
+def _out_of_scope(name, where):
+    def init(self, *args, **kwargs):
+        raise NotImplementedError(
+            f"{name} (reference pyramidkv_utils.py:{where}) is outside the scope of pyramidkv_amd (SURVEY.md section 2: "
+            "CAM / L2Norm / ThinK are not on the update_kv hot path); the name exists so that the reference's "
+            "llama_model.py / mistral_model.py import this module unchanged")
+    init.__name__ = name
+    init.__doc__ = f"Placeholder for the reference's {name} (:{where}); raises NotImplementedError when called."
+    return init
+
+
+# llama_model.py:16, llama_model_think.py:16 and mistral_model.py:19 import these three from this module.
+init_CAM = _out_of_scope("init_CAM", "970-988")
+init_l2norm = _out_of_scope("init_l2norm", "954-968")
+init_think = _out_of_scope("init_think", "926-952")
 
 
 def headkv_head_capacity(head_scores, num_hidden_layers, num_attention_heads, max_capacity_prompts, head_beta=1.01):
