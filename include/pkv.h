@@ -135,6 +135,28 @@ int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, 
                    double floor_ratio, int32_t normalize, int32_t* head_capacity, void* ws,
                    size_t ws_bytes, pkv_stream_t stream);
 
+/* The same budgets WITHOUT a full sort: one head can receive at most H*base entries of the global top-(H*base), so the
+ * first M = min(L, H*base) entries of every head's descending order decide everything.  top_idx: int32 [H][idx_stride],
+ * row h = pkv_topk(scores row h, k = M) (canonical order); scores: dtype [H][scores_stride], the un-sorted rows of length
+ * L (the sum over all scores of :710 is taken from them).  M >= min(L, H*base) is checked.  Same ws as pkv_ada_budget.
+ * head_lens / cu_klen (both or neither; device int32 [H] / [H+1]): when given, the var-len metadata of pkv_ada_metadata
+ * for `window` is written by the same launch. */
+int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const void* scores, int64_t scores_stride,
+                        const int32_t* top_idx, int64_t idx_stride, int32_t base_capacity, double floor_ratio,
+                        int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens, int32_t* cu_klen,
+                        void* ws, size_t ws_bytes, pkv_stream_t stream);
+
+/* Fused front half of AdaKVCluster.update_kv / HeadKVCluster.update_kv (:674-731 / :808-852) in ONE call: window score
+ * (d->reduce = PKV_REDUCE_MEAN, :661) -> top-M indices of every head (d->topk = M, canonical order) -> head budgets +
+ * var-len metadata.  Ada-SnapKV: given_capacity = NULL, M >= min(S-w, H*base); writes head_capacity, head_lens, cu_klen.
+ * HeadKV: given_capacity = device int32 [H] (host-derived, :855), M >= max capacity; writes head_lens, cu_klen only.
+ * The host then reads the capacities back (klen_sum / max_seqlen_k are Python ints at the boundary, :685-686; the
+ * reference has the same sync at :718) and calls pkv_gather_flat(top_idx, idx_stride = M, ...).  ws: pkv_workspace_bytes(d). */
+int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base_capacity, double floor_ratio,
+                   int32_t normalize, const int32_t* given_capacity, int32_t* top_idx, int32_t* head_capacity,
+                   int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens /* [H] inclusive prefix (:687), may be NULL */,
+                   void* ws, size_t ws_bytes, pkv_stream_t stream);
+
 /* Var-len metadata (:682-698) from head_capacity: head_lens[H] = cap_h + w, cu_klen[H+1]
  * (exclusive prefix + total).  All device int32. */
 int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, int32_t* head_lens,
@@ -142,10 +164,12 @@ int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, in
 
 /* Flat gather (:733-757): for head h rows sorted_idx[h][0..cap_h) then the window tail, written at
  * row cu_klen[h] of the flat [sum_h(cap_h+w), D] outputs.  B must be 1.  d->topk, if > 0, is an upper
- * bound on max_h cap_h (sizes the launch); 0 = unknown (S-w). */
+ * bound on max_h cap_h (sizes the launch); 0 = unknown (S-w).  out_rows = rows k_out / v_out hold (> 0: nothing is
+ * stored at or beyond it - the outputs may be sized by a bound before the capacities are known on the host; 0 = not
+ * checked). */
 int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32_t* sorted_idx,
                     int64_t idx_stride, const int32_t* head_capacity, const int32_t* cu_klen,
-                    void* k_out, void* v_out, pkv_stream_t stream);
+                    void* k_out, void* v_out, int64_t out_rows, pkv_stream_t stream);
 
 /* Decode-time flat-cache append (csrc/csrc/cuda_api.cu:11-85 update_flatten_view): out has
  * origin_rows + H rows; head h: copy head_lens[h] rows from cache row cu_klen[h] to out row

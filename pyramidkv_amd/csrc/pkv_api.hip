@@ -111,7 +111,7 @@ size_t topk_tmp_bytes(int rows, int L, int k);
 
 struct WsLayout {
   int Sp, nT, Lp;
-  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_tk, tk_bytes, off_rowstat, total;
+  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_tk, tk_bytes, off_ada, off_ada_list, off_rowstat, total;
 };
 
 WsLayout ws_layout(const pkv_desc* d) {
@@ -128,6 +128,8 @@ WsLayout ws_layout(const pkv_desc* d) {
   w.off_cmax = o;    o = align_up(o + (size_t)d->B * d->H * (w.Lp / 8) * 2, 256);
   w.tk_bytes = d->topk > 0 ? topk_tmp_bytes(d->B * d->H, d->S - d->window, d->topk) : 0;      // long-row top-k scratch (0 up to 57 344 keys)
   w.off_tk = o;      o = align_up(o + w.tk_bytes, 256);
+  w.off_ada = o;     o = align_up(o + 1024 + (size_t)2 * d->H * 256 * 4, 256);                 // Ada-SnapKV budget scratch (pkv_ada_select)
+  w.off_ada_list = o; o = align_up(o + (size_t)d->H * align_up((size_t)(d->topk > 0 ? d->topk : 1), 8) * 2, 256);   // looked-up top-M lists
   w.off_rowstat = o; o = align_up(o + (size_t)d->B * d->H * d->S * sizeof(float2), 256);   // H2O only
   w.total = o;
   return w;
@@ -277,6 +279,7 @@ GatherParams make_gather(const pkv_desc* d, const void* k, const void* v, void* 
   g.kptr = k; g.vptr = v; g.k_out = ko; g.v_out = vo;
   g.idx = nullptr; g.idx_stride = 0; g.head_k = nullptr; g.cu_rows = nullptr; g.wgtrace = g_wg_trace;
   g.rpt = gather_rpt(); g.xcd_map = gather_xcd(); g.nblk = 0;
+  g.out_rows = (int64_t)d->B * d->H * (d->topk + d->window);          // dense layout; pkv_gather_flat overrides it
   g.B = d->B; g.H = d->H; g.S = d->S; g.w = d->window; g.nsel = d->topk; g.G = d->kv_group;
   g.ks_b = d->k_stride[0]; g.ks_h = d->k_stride[1]; g.ks_s = d->k_stride[2];
   g.vs_b = d->v_stride[0]; g.vs_h = d->v_stride[1]; g.vs_s = d->v_stride[2];
@@ -445,13 +448,83 @@ int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, 
   if (H < 1 || H > 256 || L < 1 || base_capacity < 1 || base_capacity > L) return PKV_ERR_SHAPE;
   if (ws_bytes < 1024 + (size_t)2 * H * 256 * 4) return PKV_ERR_WORKSPACE;
   BudgetParams bp;
+  bp.sorted_idx = nullptr; bp.idx_stride = 0; bp.scores = nullptr; bp.scores_stride = 0; bp.Lrow = L;
   bp.sorted_val = sorted_val; bp.H = H; bp.L = L; bp.base = base_capacity;
   bp.one_minus_floor = (float)(1.0 - floor_ratio);                    // python double, then the fp32 scalar of :719
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);     // int(base_capacity * floor_ratio) (:632)
-  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws;
+  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr;
+  bp.window = 0; bp.head_lens_out = nullptr; bp.cu_klen_out = nullptr; bp.cu_headlens_out = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(dtype, bp, st);
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const void* scores, int64_t scores_stride,
+                        const int32_t* top_idx, int64_t idx_stride, int32_t base_capacity, double floor_ratio,
+                        int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens, int32_t* cu_klen,
+                        void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (!scores || !top_idx || !head_capacity || !ws) return PKV_ERR_NULL;
+  if ((head_lens == nullptr) != (cu_klen == nullptr)) return PKV_ERR_NULL;
+  if (H < 1 || H > 256 || L < 1 || base_capacity < 1 || base_capacity > L) return PKV_ERR_SHAPE;
+  // M must cover everything one head can receive: min(L, H*base) (a shorter list could cut a head's share off)
+  const int64_t need = std::min<int64_t>(L, (int64_t)H * base_capacity);
+  if (M < need || M > L || scores_stride < L || idx_stride < M) return PKV_ERR_SHAPE;
+  if (M > 65536) return PKV_ERR_UNSUPPORTED;          // the staged list must fit in LDS (2 bytes per entry)
+  if (ws_bytes < 1024 + (size_t)2 * H * 256 * 4) return PKV_ERR_WORKSPACE;
+  BudgetParams bp;
+  bp.sorted_val = nullptr; bp.sorted_idx = top_idx; bp.idx_stride = idx_stride; bp.scores = scores; bp.scores_stride = scores_stride;
+  bp.Lrow = L; bp.H = H; bp.L = M; bp.base = base_capacity;
+  bp.one_minus_floor = (float)(1.0 - floor_ratio);
+  bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
+  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr;
+  bp.window = window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(PKV_K_BUDGET, st);
+  hipError_t e = launch_budget(dtype, bp, st);
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base_capacity, double floor_ratio,
+                   int32_t normalize, const int32_t* given_capacity, int32_t* top_idx, int32_t* head_capacity,
+                   int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  if (d->B != 1) return PKV_ERR_SHAPE;                     // reference asserts bsz == 1 (:724)
+  if (!q || !k || !top_idx || !head_lens || !cu_klen || !ws) return PKV_ERR_NULL;
+  if (!given_capacity && !head_capacity) return PKV_ERR_NULL;
+  if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
+  const int L = d->S - d->window, M = d->topk, H = d->H;
+  if (!given_capacity) {
+    if (H > 256 || base_capacity < 1 || base_capacity > L) return PKV_ERR_SHAPE;
+    if (M < std::min<int64_t>(L, (int64_t)H * base_capacity)) return PKV_ERR_SHAPE;
+    if (M > 65536) return PKV_ERR_UNSUPPORTED;
+  }
+  WsLayout W = ws_layout(d);
+  if (ws_bytes < W.off_rowstat) return PKV_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* w = static_cast<char*>(ws);
+  void* scores = w + W.off_scores;
+  const bool cm = env_int("PKV_TOPK_CMAX", 1) != 0;
+  rc = do_score_window(d, q, k, scores, W.Lp, w, W, st, cm);
+  if (rc) return rc;
+  rc = do_topk(d->dtype, H, L, M, scores, W.Lp, nullptr, top_idx, M, st, cm ? w + W.off_cmax : nullptr, W.Lp / 8,
+               w + W.off_tk, W.tk_bytes);
+  if (rc) return rc;
+  if (given_capacity) {                                    // HeadKV: capacities come from the host (:855); metadata only
+    hipError_t e = launch_ada_metadata(H, d->window, given_capacity, head_lens, cu_klen, st, cu_headlens);
+    return e == hipSuccess ? PKV_OK : hip_fail(e);
+  }
+  BudgetParams bp;
+  bp.sorted_val = nullptr; bp.sorted_idx = top_idx; bp.idx_stride = M; bp.scores = scores; bp.scores_stride = W.Lp;
+  bp.Lrow = L; bp.H = H; bp.L = M; bp.base = base_capacity;
+  bp.one_minus_floor = (float)(1.0 - floor_ratio);
+  bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
+  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = w + W.off_ada; bp.list_ws = w + W.off_ada_list;
+  bp.window = d->window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
+  ProfScope ps(PKV_K_BUDGET, st);
+  hipError_t e = launch_budget(d->dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }
 
@@ -465,7 +538,7 @@ int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, in
 
 int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32_t* sorted_idx,
                     int64_t idx_stride, const int32_t* head_capacity, const int32_t* cu_klen,
-                    void* k_out, void* v_out, pkv_stream_t stream) {
+                    void* k_out, void* v_out, int64_t out_rows, pkv_stream_t stream) {
   int rc = check_desc(d, false, false);
   if (rc) return rc;
   if (d->B != 1) return PKV_ERR_SHAPE;   // reference asserts bsz == 1 (:724)
@@ -473,6 +546,7 @@ int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32
   if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out)) return PKV_ERR_ALIGN;
   GatherParams g = make_gather(d, k, v, k_out, v_out);
   g.idx = sorted_idx; g.idx_stride = idx_stride; g.head_k = head_capacity; g.cu_rows = cu_klen;
+  g.out_rows = out_rows > 0 ? out_rows : INT64_MAX;
   // worst case rows per head: d->topk if the caller knows max(cap_h), else every past token
   const int max_sel = d->topk > 0 ? d->topk : d->S - d->window;
   return do_gather(g, max_sel + d->window, static_cast<hipStream_t>(stream));

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int r = r_blk + j * 16 + slot;
-    ok[j] = r < nrows;
+    ok[j] = r < nrows && out_row0 + r < p.out_rows;          // out_rows: rows the output buffers hold (flat layout: a bound)
     // a selected index outside [0, L) (the reference's gather raises there) is clamped: never an out-of-bounds read
     const int g = min(max(gi[j], 0), L - 1);
     const int s = (r < nsel) ? g : L + (r - nsel);

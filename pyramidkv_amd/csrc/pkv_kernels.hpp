@@ -109,15 +109,26 @@ struct GatherParams {
   int rpt;                   // rows per lane and tensor: 2, 4 or 8 (16*rpt rows per workgroup)
   int xcd_map;               // place the blocks of head bh on XCD bh % 8 (where top-k wrote its indices)
   int nblk;                  // row blocks per head (set by launch_gather)
+  int64_t out_rows;          // rows the output buffers hold: nothing is stored at or beyond it
 };
 
 struct BudgetParams {
-  const void* sorted_val;    // [H][L] descending
-  int H, L, base;
+  const void* sorted_val;    // [H][L] descending, or null when the list is given as (sorted_idx, scores)
+  const int32_t* sorted_idx; // [H][idx_stride]: the first L entries of every head's descending order (top-L indices), or null
+  int64_t idx_stride;
+  const void* scores;        // [H][scores_stride] un-sorted score rows of length Lrow (with sorted_idx)
+  int64_t scores_stride;
+  int Lrow;
+  int H, L, base;            // L = entries per head in the sorted list
   float one_minus_floor;     // (float)(1.0 - floor_ratio), the fp32 scalar ATen multiplies by
   int floor_capacity;        // int(base * floor_ratio)
   int normalize;
   int32_t* head_capacity;    // [H]
+  int window;                // with head_lens_out / cu_klen_out: the var-len metadata of :682-691 from the same launch
+  int32_t* head_lens_out;    // [H] or null
+  int32_t* cu_klen_out;      // [H+1] or null
+  int32_t* cu_headlens_out;  // [H] inclusive prefix (:687) or null
+  void* list_ws;             // optional: H * roundup(L,8) * 2 bytes, 16-B aligned - the looked-up lists travel through it
   void* ws;                  // 1024 B ratios + 2 * H*256 int32
 };
 
@@ -156,7 +167,8 @@ hipError_t launch_topk_merge_finish(int rows, int k, const int32_t* cand_idx, in
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);
 hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
-hipError_t launch_ada_metadata(int H, int w, const int32_t* cap, int32_t* head_lens, int32_t* cu_klen, hipStream_t st);
+hipError_t launch_ada_metadata(int H, int w, const int32_t* cap, int32_t* head_lens, int32_t* cu_klen, hipStream_t st,
+                               int32_t* cu_headlens = nullptr);
 hipError_t launch_flatten(const FlattenParams& p, hipStream_t st);
 hipError_t launch_debug_exp(const float* in, float* out, int64_t n, hipStream_t st);
 hipError_t launch_debug_round(int dtype, const float* in, uint16_t* out, int64_t n, hipStream_t st);

@@ -214,6 +214,53 @@ def ada_budget(sorted_val: torch.Tensor, base_capacity: int, floor_ratio: float,
     return cap
 
 
+def ada_budget_topm(scores: torch.Tensor, top_idx: torch.Tensor, base_capacity: int, floor_ratio: float,
+                    normalize: bool, window: Optional[int] = None):
+    """pyramidkv_utils.py:709-719 without the full sort of :706: scores [H,L] (un-sorted), top_idx int32 [H,M] = the first
+    M >= min(L, H*base) entries of every head's descending order (``topk(scores, M)``) -> int32 head_capacity [H].
+    With ``window`` the var-len metadata of :682-691 comes out of the same launch: (cap, head_lens [H], cu_klen [H+1])."""
+    _require_gpu(scores, top_idx)
+    assert scores.dim() == 2 and top_idx.dim() == 2 and scores.stride(-1) == 1 and top_idx.stride(-1) == 1
+    H, L = scores.shape
+    M = top_idx.shape[1]
+    dev = scores.device
+    out = torch.empty(2 * H + 1 + H, dtype=torch.int32, device=dev)          # cap | head_lens | cu_klen (one allocation)
+    cap, head_lens, cu = out[:H], out[H:2 * H], out[2 * H:]
+    nb = 1024 + 2 * H * 256 * 4
+    with torch.cuda.device(dev):
+        ws = workspace(nb, dev)
+        N.check(N.lib.pkv_ada_budget_topm(N.dtype_code(scores.dtype), H, L, M, scores.data_ptr(), scores.stride(0),
+                                          top_idx.data_ptr(), top_idx.stride(0), base_capacity, float(floor_ratio),
+                                          1 if normalize else 0, int(window or 0), cap.data_ptr(),
+                                          head_lens.data_ptr() if window is not None else None,
+                                          cu.data_ptr() if window is not None else None,
+                                          ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_ada_budget_topm")
+    return (cap, head_lens, cu) if window is not None else cap
+
+
+def ada_select(q, k, window: int, pooling, kernel_size: int, M: int, base_capacity: int = 0, floor_ratio: float = 0.0,
+               normalize: bool = False, given_capacity: Optional[torch.Tensor] = None, scale_mode: str = "div",
+               kv_group: int = 1):
+    """Front half of AdaKVCluster / HeadKVCluster.update_kv in one C call (pkv_ada_select): mean-reduced window score ->
+    top-M indices per head -> head budgets (or the given ones) + var-len metadata.
+    Returns (top_idx int32 [H,M], head_capacity int32 [H], head_lens int32 [H], cu_klen int32 [H+1], cu_headlens int32 [H])."""
+    _require_gpu(q, k)
+    q, k = _rowmajor(q), _rowmajor(k)
+    H = q.shape[1]
+    dev = k.device
+    with torch.cuda.device(dev):
+        d = make_desc(q, k, None, window, pooling, kernel_size, "mean", scale_mode, M, kv_group)
+        ws = workspace(N.lib.pkv_workspace_bytes(d), dev)
+        top_idx = torch.empty(H, M, dtype=torch.int32, device=dev)
+        meta = torch.empty(4 * H + 1, dtype=torch.int32, device=dev)       # cap | head_lens | cu_klen | cu_headlens (one allocation)
+        cap, head_lens, cu, cuh = meta[:H], meta[H:2 * H], meta[2 * H:3 * H + 1], meta[3 * H + 1:]
+        N.check(N.lib.pkv_ada_select(d, q.data_ptr(), k.data_ptr(), base_capacity, float(floor_ratio), 1 if normalize else 0,
+                                     given_capacity.data_ptr() if given_capacity is not None else None, top_idx.data_ptr(),
+                                     cap.data_ptr(), head_lens.data_ptr(), cu.data_ptr(), cuh.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     N.stream_ptr()), "pkv_ada_select")
+    return top_idx, (given_capacity if given_capacity is not None else cap), head_lens, cu, cuh
+
+
 def ada_metadata(head_capacity: torch.Tensor, window: int):
     """pyramidkv_utils.py:682-691.  -> (head_lens int32 [H], cu_klen int32 [H+1])."""
     _require_gpu(head_capacity)
@@ -238,7 +285,7 @@ def gather_flat(k, v, sorted_idx: torch.Tensor, head_capacity: torch.Tensor, cu_
         ko = torch.empty(total_rows, D, dtype=k.dtype, device=k.device)
         vo = torch.empty_like(ko)
         N.check(N.lib.pkv_gather_flat(d, k.data_ptr(), v.data_ptr(), sorted_idx.data_ptr(), sorted_idx.stride(0),
-                                      head_capacity.data_ptr(), cu_klen.data_ptr(), ko.data_ptr(), vo.data_ptr(),
+                                      head_capacity.data_ptr(), cu_klen.data_ptr(), ko.data_ptr(), vo.data_ptr(), total_rows,
                                       N.stream_ptr()), "pkv_gather_flat")
     return ko, vo
 

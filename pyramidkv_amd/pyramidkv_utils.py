@@ -222,6 +222,25 @@ class StreamingLLMKVCluster:
         return _repeat_kv(kc, g), _repeat_kv(vc, g)       # every head of a group keeps the same tokens
 
 
+_PINNED = {}
+
+
+def _read_back(t: torch.Tensor):
+    """Small device int32 vector -> Python list through a cached pinned buffer (the one host sync of Ada-SnapKV, as the
+    reference's ``.item()`` at :718): an asynchronous copy + a stream synchronise instead of a pageable blocking copy."""
+    n = t.numel()
+    buf = _PINNED.get(n)
+    if buf is None:
+        buf = torch.empty(n, dtype=t.dtype, pin_memory=True)
+        _PINNED[n] = buf
+    buf.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return buf.tolist()
+
+
+_ADA_TOPM_MAX = 8192      # longest per-head list taken from the top-k kernel; beyond it the rows are sorted completely
+
+
 class _FlatPolicy:
     """Shared var-len metadata of AdaKV / HeadKV (reference :682-698)."""
 
@@ -235,11 +254,12 @@ class _FlatPolicy:
 
     _CONST = {}     # (num_heads, device) -> the four read-only index vectors (the decode step only adds cu_offset to cu_klen)
 
-    def _init_metadata(self, num_heads, head_lens, cu_klen, klen_sum, max_seqlen_k, device):
+    def _init_metadata(self, num_heads, head_lens, cu_klen, klen_sum, max_seqlen_k, device, cu_headlens=None):
         self.head_lens = head_lens                                                   # int32 [H]          :684
         self.klen_sum = klen_sum                                                     #                    :685
         self.max_seqlen_k = max_seqlen_k                                             #                    :686
-        self.cu_headlens = cu_klen[1:].clone()                                       # inclusive prefix   :687
+        # inclusive prefix :687 (a separate tensor: the decode steps shift cu_klen in place, llama_model.py:2374)
+        self.cu_headlens = cu_headlens if cu_headlens is not None else cu_klen[1:].clone()
         self.cu_klen = cu_klen                                                       # int32 [H+1]        :689-691
         key = (num_heads, str(device))
         const = _FlatPolicy._CONST.get(key)
@@ -255,27 +275,45 @@ class _FlatPolicy:
         if self.pooling not in ('avgpool', 'maxpool'):
             raise ValueError('Pooling method not supported')
         return ops.score_window(query_states, key_states, self.window_size, self.pooling, self.kernel_size,
-                                reduce="mean", scale_mode=_cfg.scale_mode)
+                                reduce="mean", scale_mode=_cfg.scale_mode,
+                                kv_group=_unexpanded_group(key_states, query_states))
+
+    accepts_unexpanded_kv = True      # K/V may arrive with H/g heads (before repeat_kv): every KV head is read once per group
 
     def _passthrough(self, key_states, value_states, num_heads, q_len, head_dim):
+        g = num_heads // key_states.shape[1]
+        key_states, value_states = _repeat_kv(key_states, g), _repeat_kv(value_states, g)
         dev = key_states.device
         head_lens = torch.full((num_heads,), q_len, dtype=torch.int32, device=dev)
         cu = torch.arange(0, num_heads + 1, dtype=torch.int32, device=dev) * q_len
         self._init_metadata(num_heads, head_lens, cu, q_len * num_heads, q_len, dev)  # :701
         return key_states.reshape(-1, head_dim), value_states.reshape(-1, head_dim)   # :703
 
-    def _flat_from_capacity(self, key_states, value_states, sorted_idx, cap_dev, num_heads, caps_host=None):
+    def _flat_from_capacity(self, key_states, value_states, sorted_idx, cap_dev, num_heads, caps_host=None, meta=None,
+                            rows_bound=None):
         """Flat gather + metadata.  The boundary exposes klen_sum / max_seqlen_k as Python ints (:685-686), which needs the
         capacities on the host: HeadKV knows them already (``caps_host``), Ada-SnapKV reads them back (one host sync, as the
-        reference's ``.item()`` at :718; launching the gather ahead of that read-back into bound-sized buffers was measured
-        and gains nothing)."""
-        head_lens, cu = ops.ada_metadata(cap_dev, self.window_size)
-        caps = caps_host if caps_host is not None else cap_dev.tolist()
-        klen_sum = sum(caps) + num_heads * self.window_size
-        max_cap = max(caps)
-        kf, vf = ops.gather_flat(key_states, value_states, sorted_idx, cap_dev, cu, self.window_size, klen_sum,
-                                 max_cap=max_cap)
-        self._init_metadata(num_heads, head_lens, cu, klen_sum, max_cap + self.window_size, key_states.device)
+        reference's ``.item()`` at :718)."""
+        head_lens, cu = meta[:2] if meta is not None else ops.ada_metadata(cap_dev, self.window_size)
+        g = num_heads // key_states.shape[1]
+        if caps_host is None and rows_bound is not None:
+            # Ada-SnapKV on the fused path: the flat gather runs on the device-resident capacities BEFORE the one host
+            # sync, into buffers sized by the bound sum_h cap_h <= H*base + H/2 (:719 rounds every head by < 1/2); the
+            # read-back then only narrows the views.  Nothing but the sync latency is left between the kernels and the return.
+            kf, vf = ops.gather_flat(key_states, value_states, sorted_idx, cap_dev, cu, self.window_size, rows_bound,
+                                     max_cap=sorted_idx.shape[1], kv_group=g)
+            caps = _read_back(cap_dev)
+            klen_sum = sum(caps) + num_heads * self.window_size
+            max_cap = max(caps)
+            kf, vf = kf[:klen_sum], vf[:klen_sum]
+        else:
+            caps = caps_host if caps_host is not None else _read_back(cap_dev)
+            klen_sum = sum(caps) + num_heads * self.window_size
+            max_cap = max(caps)
+            kf, vf = ops.gather_flat(key_states, value_states, sorted_idx, cap_dev, cu, self.window_size, klen_sum,
+                                     max_cap=max_cap, kv_group=g)
+        self._init_metadata(num_heads, head_lens, cu, klen_sum, max_cap + self.window_size, key_states.device,
+                            cu_headlens=meta[2] if meta is not None and len(meta) > 2 else None)
         self.head_capacity_last = caps
         return kf, vf
 
@@ -303,6 +341,21 @@ class AdaKVCluster(_FlatPolicy):
         if self.base_capacity > L:                                                   # :700
             return self._passthrough(key_states, value_states, num_heads, q_len, head_dim)
         assert bsz == 1                                                              # :724
+        # :706 sorts every row completely; what :709-757 consume of that order is bounded: one head can receive at most
+        # H*base entries of the global top-(H*base) (:712-717), so the first M = min(L, H*base) entries per head decide the
+        # budgets AND hold every index the gather takes (cap_h <= M).  They come from the top-k kernel (no full sort);
+        # score -> top-M -> budgets -> metadata is ONE C call.
+        M = min(L, num_heads * self.base_capacity)
+        if M <= _ADA_TOPM_MAX:
+            if self.pooling not in ('avgpool', 'maxpool'):
+                raise ValueError('Pooling method not supported')
+            sorted_idx, cap, head_lens, cu, cuh = ops.ada_select(
+                query_states, key_states, self.window_size, self.pooling, self.kernel_size, M, self.base_capacity,
+                self.floor_ratio, bool(self.normalize), scale_mode=_cfg.scale_mode,
+                kv_group=_unexpanded_group(key_states, query_states))               # :647-672, :706-719, :682-691
+            bound = num_heads * self.base_capacity + num_heads + num_heads * self.window_size
+            return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, meta=(head_lens, cu, cuh),
+                                            rows_bound=bound)
         attn_score = self._scores(key_states, query_states)                          # [1,H,L]
         sorted_idx, sorted_val = ops.sort_rows(attn_score[0])                        # :706
         cap = ops.ada_budget(sorted_val, self.base_capacity, self.floor_ratio, bool(self.normalize))  # :709-719
@@ -329,10 +382,22 @@ class HeadKVCluster(_FlatPolicy):
         if self.base_capacity > L:                                                   # :834
             return self._passthrough(key_states, value_states, num_heads, q_len, head_dim)
         assert bsz == 1                                                              # :845
+        caps = [min(int(self.head_adaptive_capacity[self.layer_idx][h]), L) for h in range(num_heads)]  # :855 slice
+        key = (tuple(caps), str(key_states.device))
+        if getattr(self, "_cap_key", None) != key:               # the per-layer capacities are constants: upload them once
+            self._cap_key, self._cap_dev = key, torch.tensor(caps, dtype=torch.int32, device=key_states.device)
+        cap = self._cap_dev
+        # :840 sorts every row completely and :855 keeps the first cap_h entries: a top-k with k = max_h cap_h holds them all
+        if max(caps) <= _ADA_TOPM_MAX:
+            if self.pooling not in ('avgpool', 'maxpool'):
+                raise ValueError('Pooling method not supported')
+            sorted_idx, _, head_lens, cu, cuh = ops.ada_select(
+                query_states, key_states, self.window_size, self.pooling, self.kernel_size, max(1, max(caps)),
+                given_capacity=cap, scale_mode=_cfg.scale_mode, kv_group=_unexpanded_group(key_states, query_states))
+            return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, caps_host=caps,
+                                            meta=(head_lens, cu, cuh))
         attn_score = self._scores(key_states, query_states)
         sorted_idx, _ = ops.sort_rows(attn_score[0], want_values=False)              # :840
-        caps = [min(int(self.head_adaptive_capacity[self.layer_idx][h]), L) for h in range(num_heads)]  # :855 slice
-        cap = torch.tensor(caps, dtype=torch.int32, device=key_states.device)
         return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, caps_host=caps)
 
 

@@ -21,6 +21,7 @@ from oracle import pkv_oracle as O
 pytestmark = pytest.mark.gpu
 
 SCORE_MISMATCH_FRAC = 2e-3
+H2O_MISMATCH_FRAC = 1e-3      # H2O column sums (S rows, fp32): measured 0 - 6e-5
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda"
 REPORT = {}
@@ -270,8 +271,8 @@ def test_h2o_scores(P, dt):
         got = P.ops.score_h2o(q.to(DEV), k.to(DEV), w).cpu()
         frac, mx = score_diff(got, want)
         _report(f"h2o_scores/{dt}/S{S}", dict(mismatch_frac=frac, max_ulp=mx))
-        # column sums over S rows in fp32: summation order differs, allow a larger (still 1-ulp) fraction
-        assert mx <= 1 and frac <= 0.05, (frac, mx)
+        # column sums over S rows in fp32: the summation order differs from ATen's (measured: 0 - 6e-5 of the elements)
+        assert mx <= 1 and frac <= H2O_MISMATCH_FRAC, (frac, mx)
 
 
 # ----------------------------------------------------------------------------------------- end to end
@@ -297,7 +298,10 @@ def test_compress_self_consistent_and_match_rate(P, dt, S, cap):
     same_seq = (out[2].cpu().long() == ridx).all(-1).float().mean().item()
     same_set = float(np.mean([set(out[2][0, h].tolist()) == set(ridx[0, h].tolist()) for h in range(H)]))
     _report(f"e2e_gauss/{dt}/S{S}cap{cap}", dict(heads_identical_sequence=same_seq, heads_identical_set=same_set))
-    assert same_set >= 0.5
+    # bars = what was measured: every head selects the oracle's token SET; the ORDER is the oracle's too, except that one
+    # fp16 budget-2048 head of this fixture carries a 1-ulp score difference between two adjacent selected tokens
+    assert same_set == 1.0
+    assert same_seq >= (0.875 if (dt, cap) == ("fp16", 2048) else 1.0)
 
 
 def test_compress_randomised_configs(P):
@@ -474,10 +478,9 @@ def test_adakv_cluster_metadata_and_consistency(P):
     assert cl.cu_klen.cpu().tolist() == [0] + np.cumsum(cl.head_lens.cpu().numpy()).tolist()
     assert cl.cu_qlen.cpu().tolist() == list(range(H + 1)) and cl.cu_offset.cpu().tolist() == list(range(H + 1))
     assert cl.max_seqlen_k == int(cl.head_lens.max())
-    same = cl.head_lens.cpu().tolist() == meta.head_lens.tolist()
-    _report("adakv/head_lens_identical_to_oracle", same)
-    if same:
-        _report("adakv/kv_identical_to_oracle", bool(torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr)))
+    assert cl.cu_headlens.cpu().tolist() == np.cumsum(cl.head_lens.cpu().numpy()).tolist()          # :687
+    assert cl.head_lens.cpu().tolist() == meta.head_lens.tolist()
+    assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr)
     # not-compressed branch (:700-703)
     q2, k2, v2 = make_qkv(1, 2, 40, 128, "bf16", "gauss", 53)
     cl2 = P.AdaKVCluster(window_size=8, kernel_size=7, pooling="maxpool", max_capacity_prompt=64, floor=0.2, normalize=True)
@@ -694,8 +697,9 @@ def test_golden_fixtures_through_hip_path(P):
                     roff += n
             stats[c["name"]] = dict(same_score_sequence_as_reference=bool(equiv), bit_identical_to_reference=exact)
     _report("golden_through_hip", stats)
-    rate = np.mean([s["same_score_sequence_as_reference"] for s in stats.values()])
-    assert rate >= 0.9, stats
+    # every fixture: the HIP path selects, position by position, the score values the REAL reference selected
+    bad = [n for n, s in stats.items() if not s["same_score_sequence_as_reference"]]
+    assert not bad, bad
 
 
 # ----------------------------------------------------------------------------------------- adapter on the device
@@ -714,8 +718,17 @@ def test_replace_llama_end_to_end_on_gpu(P):
     ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(1)).to(DEV)
     with torch.no_grad():
         base = model(ids).logits
+    captured = {}
+    orig_update = P.PyramidKVCluster.update_kv
+
+    def recording_update(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
+        if self.layer_idx not in captured:      # the prefill call of every layer (K/V arrive un-expanded: 2 KV heads)
+            captured[self.layer_idx] = tuple(t.detach().clone() for t in (key_states, query_states, value_states))
+        return orig_update(self, key_states, query_states, value_states, attention_mask, num_key_value_groups)
+
     try:
         mp.replace_llama("pyramidkv")
+        P.PyramidKVCluster.update_kv = recording_update
         for layer in model.model.layers:
             c = layer.self_attn.config
             c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = w, cap, 7, "maxpool", None
@@ -727,7 +740,22 @@ def test_replace_llama_end_to_end_on_gpu(P):
         assert lens == [O.pyramid_budget(cap, w, 4, i, S)[1] + w + 3 for i in range(4)]
         assert torch.allclose(full.logits.float(), base.float(), atol=2e-2, rtol=2e-2)
         assert isinstance(model.model.layers[0].self_attn.kv_cluster, P.PyramidKVCluster)
+        # the compacted cache of EVERY layer == the oracle's update_kv on that layer's own K/Q/V (K/V expanded by repeat_kv as
+        # the reference hands them over, llama_model.py:158-159); the 3 rows behind it are the decode steps' appends
+        assert sorted(captured) == [0, 1, 2, 3]
+        for li in range(4):
+            kx, qx, vx = (t.cpu() for t in captured[li])
+            g = qx.shape[1] // kx.shape[1]
+            kx = kx[:, :, None].expand(1, kx.shape[1], g, S, 128).reshape(1, -1, S, 128).contiguous()
+            vx = vx[:, :, None].expand(1, vx.shape[1], g, S, 128).reshape(1, -1, S, 128).contiguous()
+            kr, vr = O.pyramidkv_update_kv(kx, qx, vx, w, cap, 7, "maxpool", 4, li)
+            n = kr.shape[2]
+            lay = out.past_key_values.layers[li]
+            assert torch.equal(lay.keys[:, :, :n].cpu(), kr) and torch.equal(lay.values[:, :, :n].cpu(), vr), li
+        # the cache reports the TRUE sequence length (positions), the layers the compacted one (masks)
+        assert out.past_key_values.get_seq_length() == S + 3
     finally:
+        P.PyramidKVCluster.update_kv = orig_update
         mp.restore()
 
 
@@ -923,7 +951,7 @@ def test_h2o_scores_8k_blocked_oracle(P):
     got = P.ops.score_h2o(q.to(DEV), k.to(DEV), 8).cpu()
     frac, mx = score_diff(got, want)
     _report("h2o_scores/bf16/S8192", dict(mismatch_frac=frac, max_ulp=mx))
-    assert mx <= 1 and frac <= 0.05, (frac, mx)
+    assert mx <= 1 and frac <= H2O_MISMATCH_FRAC, (frac, mx)
 
 
 def test_adakv_32k_vs_oracle(P):
@@ -938,7 +966,7 @@ def test_adakv_32k_vs_oracle(P):
     _report("adakv_32k", dict(head_lens_identical=same_lens, kv_identical=same_kv, head_lens=cl.head_lens.cpu().tolist()))
     assert int(cl.head_lens.sum()) == kf.shape[0] == cl.klen_sum
     assert abs(int(cl.head_lens.sum()) - H * cap) <= H              # rounding of the per-head budgets (:719)
-    assert same_lens
+    assert same_lens and same_kv
 
 
 def test_config_knobs_gqa_dedup_and_scale_mode(P):

@@ -284,3 +284,83 @@ def test_flat_cache_methods_generate(patched, method, family):
         for layer in model.model.layers:
             if hasattr(layer.self_attn, "kv_cluster"):
                 del layer.self_attn.kv_cluster
+
+
+# ----------------------------------------------------------------------------------------- round-2 advisor findings
+def test_sliding_window_model_keeps_the_compacted_rows(patched):
+    """Mistral-7B-v0.1 style config (sliding_window set): transformers 5 builds DynamicSlidingWindowLayer entries that crop
+    to the LAST sliding_window - 1 rows on update - the compacted cache stores its top-scored rows FIRST, so the crop would
+    evict exactly them.  The adapter holds compacted layers in plain DynamicLayer entries (the reference's 4.44 cache never
+    crops): cap + new tokens rows survive."""
+    from transformers import MistralConfig, MistralForCausalLM, DynamicCache
+    torch.manual_seed(0)
+    cfg = MistralConfig(vocab_size=97, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                        num_key_value_heads=1, head_dim=128, max_position_embeddings=4096, sliding_window=64)
+    model = MistralForCausalLM(cfg).eval()
+    S, cap, w, new = 150, 48, 8, 30
+    ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(1))
+    patched.replace_mistral("snapkv")
+    for layer in model.model.layers:
+        c = layer.self_attn.config
+        c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = w, cap, 7, "maxpool", None
+    with torch.no_grad():
+        out = model.generate(ids, max_new_tokens=new, do_sample=False, return_dict_in_generate=True,
+                             past_key_values=DynamicCache(config=cfg))
+    for lay in out.past_key_values.layers:
+        assert lay.keys.shape[2] == cap + new - 1          # nothing cropped (the stock sliding layer would hold 63 rows)
+
+
+def test_positions_follow_the_true_length_without_explicit_positions(patched):
+    """After compaction the stock cache reports the compressed length; a decode loop that does not pass position_ids /
+    cache_position would rotate the next token as position `cap` instead of S.  The adapter tracks the true token count
+    (reference: self.kv_seq_len, llama_model.py:139-145,166,170,172): decoding with and without explicit positions gives
+    the same logits."""
+    from transformers import DynamicCache
+    model = _tiny("llama")
+    S, cap, w = 150, 48, 8
+    ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(2))
+    patched.replace_llama("snapkv")
+    for layer in model.model.layers:
+        c = layer.self_attn.config
+        c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = w, cap, 7, "maxpool", None
+    outs = []
+    for explicit in (True, False):
+        cache = DynamicCache(config=model.config)
+        with torch.no_grad():
+            o = model(ids, past_key_values=cache, use_cache=True)
+            assert cache.get_seq_length() == S and cache.layers[0].keys.shape[2] == cap
+            tok = o.logits[:, -1:].argmax(-1)
+            step = []
+            for t in range(3):
+                kw = dict(position_ids=torch.tensor([[S + t]]), cache_position=torch.tensor([S + t])) if explicit else {}
+                o = model(tok, past_key_values=cache, use_cache=True, **kw)
+                step.append(o.logits.clone())
+                tok = o.logits[:, -1:].argmax(-1)
+            assert cache.get_seq_length() == S + 3 and cache.layers[0].keys.shape[2] == cap + 3
+        outs.append(torch.cat(step, 1))
+    assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-5)
+
+
+def test_module_is_a_drop_in_for_the_reference_imports():
+    """INTEGRATION.md's one-line swap (sys.modules['pyramidkv.pyramidkv_utils'] = pyramidkv_amd.pyramidkv_utils) only works if
+    every name the reference's model files import from that module exists here: llama_model.py:16,20,
+    llama_model_think.py:16,20 and mistral_model.py:19-20."""
+    import os
+    import re
+    import pyramidkv_amd.pyramidkv_utils as U
+    names = {"init_pyramidkv", "init_snapkv", "init_CAM", "init_H2O", "init_StreamingLLM", "init_l2norm", "init_adakv",
+             "init_headkv", "DynamicCacheSplitHeadFlatten"}
+    ref = "/root/reference/pyramidkv"
+    if os.path.isdir(ref):                      # in the build container: read the import lines themselves
+        for f in ("llama_model.py", "llama_model_think.py", "mistral_model.py"):
+            for line in open(os.path.join(ref, f)):
+                m = re.match(r"from pyramidkv\.pyramidkv_utils import (.+)", line)
+                if m:
+                    names |= {n.strip() for n in m.group(1).split(",") if n.strip()}
+    missing = [n for n in sorted(names) if not hasattr(U, n)]
+    assert not missing, missing
+    for n in ("init_CAM", "init_l2norm", "init_think"):        # outside the hot path: present, and loud when called
+        with pytest.raises(NotImplementedError):
+            getattr(U, n)(object())
+    x = torch.zeros(1, 2, 3, 4)
+    assert U.repeat_kv(x, 1) is x and U.repeat_kv(x, 2).shape == (1, 4, 3, 4)
