@@ -155,7 +155,10 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
 int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base_capacity, double floor_ratio,
                    int32_t normalize, const int32_t* given_capacity, int32_t* top_idx, int32_t* head_capacity,
                    int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens /* [H] inclusive prefix (:687), may be NULL */,
-                   void* ws, size_t ws_bytes, pkv_stream_t stream);
+                   int32_t* host_mirror /* may be NULL: device-visible PINNED HOST int32 [H+1]; the budget kernel stores the
+                                           capacities there, fences system-wide, then stores host_seq in [H] - the host may
+                                           poll that word instead of copying + synchronising */,
+                   int32_t host_seq, void* ws, size_t ws_bytes, pkv_stream_t stream);
 
 /* Var-len metadata (:682-698) from head_capacity: head_lens[H] = cap_h + w, cu_klen[H+1]
  * (exclusive prefix + total).  All device int32. */

@@ -10,3 +10,7 @@ scale_mode = os.environ.get("PKV_SCALE_MODE", "div")
 # repeat_kv, llama_model.py:158-159, so the other heads of a group are byte-identical copies).
 # Off by default: it is only valid when the caller really passes repeat_kv output.
 gqa_dedup = os.environ.get("PKV_GQA_DEDUP", "0") == "1"
+
+# Ada-SnapKV needs its head capacities on the host (klen_sum / max_seqlen_k are Python ints at the boundary).  1 (default):
+# the budget kernel writes them into pinned host memory and the host polls a sequence word; 0: copy + stream synchronise.
+host_poll = os.environ.get("PKV_HOST_POLL", "1") == "1"

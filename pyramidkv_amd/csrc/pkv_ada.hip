@@ -218,6 +218,17 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
     cap = (int)rintf(capf);                                                                     // torch.round: half to even
     p.head_capacity[tid] = cap;
   }
+  if (p.host_mirror) {
+    // The boundary exposes klen_sum / max_seqlen_k as Python ints (:685-686), i.e. the host needs the capacities (the
+    // reference syncs for the same reason, :718).  They are written straight into pinned host memory, made visible
+    // system-wide, then flagged: the host polls the flag instead of paying a memcpy + a stream synchronise.
+    if (tid < p.H) {
+      __hip_atomic_store(p.host_mirror + tid, cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(p.host_mirror + p.H, p.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (head_lens && cu_klen) {                     // :684, :689-691: head_lens = cap + w, cu_klen = exclusive prefix + total
     __syncthreads();
     const int n = tid < p.H ? cap + window : 0;

@@ -454,6 +454,7 @@ int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, 
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);     // int(base_capacity * floor_ratio) (:632)
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr;
   bp.window = 0; bp.head_lens_out = nullptr; bp.cu_klen_out = nullptr; bp.cu_headlens_out = nullptr;
+  bp.host_mirror = nullptr; bp.host_seq = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(dtype, bp, st);
@@ -480,6 +481,7 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr;
   bp.window = window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = nullptr;
+  bp.host_mirror = nullptr; bp.host_seq = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(dtype, bp, st);
@@ -488,7 +490,8 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
 
 int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base_capacity, double floor_ratio,
                    int32_t normalize, const int32_t* given_capacity, int32_t* top_idx, int32_t* head_capacity,
-                   int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+                   int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens, int32_t* host_mirror, int32_t host_seq,
+                   void* ws, size_t ws_bytes, pkv_stream_t stream) {
   int rc = check_desc(d, true);
   if (rc) return rc;
   if (d->B != 1) return PKV_ERR_SHAPE;                     // reference asserts bsz == 1 (:724)
@@ -523,6 +526,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = w + W.off_ada; bp.list_ws = w + W.off_ada_list;
   bp.window = d->window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
+  bp.host_mirror = host_mirror; bp.host_seq = host_seq;
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(d->dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);

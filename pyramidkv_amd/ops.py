@@ -240,7 +240,7 @@ def ada_budget_topm(scores: torch.Tensor, top_idx: torch.Tensor, base_capacity: 
 
 def ada_select(q, k, window: int, pooling, kernel_size: int, M: int, base_capacity: int = 0, floor_ratio: float = 0.0,
                normalize: bool = False, given_capacity: Optional[torch.Tensor] = None, scale_mode: str = "div",
-               kv_group: int = 1):
+               kv_group: int = 1, host_mirror: Optional[torch.Tensor] = None, host_seq: int = 0):
     """Front half of AdaKVCluster / HeadKVCluster.update_kv in one C call (pkv_ada_select): mean-reduced window score ->
     top-M indices per head -> head budgets (or the given ones) + var-len metadata.
     Returns (top_idx int32 [H,M], head_capacity int32 [H], head_lens int32 [H], cu_klen int32 [H+1], cu_headlens int32 [H])."""
@@ -256,8 +256,9 @@ def ada_select(q, k, window: int, pooling, kernel_size: int, M: int, base_capaci
         cap, head_lens, cu, cuh = meta[:H], meta[H:2 * H], meta[2 * H:3 * H + 1], meta[3 * H + 1:]
         N.check(N.lib.pkv_ada_select(d, q.data_ptr(), k.data_ptr(), base_capacity, float(floor_ratio), 1 if normalize else 0,
                                      given_capacity.data_ptr() if given_capacity is not None else None, top_idx.data_ptr(),
-                                     cap.data_ptr(), head_lens.data_ptr(), cu.data_ptr(), cuh.data_ptr(), ws.data_ptr(), ws.numel(),
-                                     N.stream_ptr()), "pkv_ada_select")
+                                     cap.data_ptr(), head_lens.data_ptr(), cu.data_ptr(), cuh.data_ptr(),
+                                     host_mirror.data_ptr() if host_mirror is not None else None, int(host_seq),
+                                     ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_ada_select")
     return top_idx, (given_capacity if given_capacity is not None else cap), head_lens, cu, cuh
 
 
