@@ -146,6 +146,14 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
                         int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens, int32_t* cu_klen,
                         void* ws, size_t ws_bytes, pkv_stream_t stream);
 
+/* Head-sharded Ada-SnapKV: the budget of :712-717 couples ALL heads, so the ranks exchange one
+ * thing - every head's ADAPTIVE list (:709-711: sorted scores x sum(top base)/sum(all), model dtype), first M entries.
+ * lists_out: dtype [H][M] for this rank's H heads; after the all-gather every rank calls pkv_ada_budget(sorted_val = the
+ * gathered lists, L = M, normalize = 0).  M >= min(S-w, H_total*base) keeps that exact (see pkv_ada_budget_topm). */
+int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t M, const void* scores, int64_t scores_stride,
+                           const int32_t* top_idx, int64_t idx_stride, int32_t base_capacity, int32_t normalize,
+                           void* lists_out, void* ws, size_t ws_bytes, pkv_stream_t stream);
+
 /* Fused front half of AdaKVCluster.update_kv / HeadKVCluster.update_kv (:674-731 / :808-852) in ONE call: window score
  * (d->reduce = PKV_REDUCE_MEAN, :661) -> top-M indices of every head (d->topk = M, canonical order) -> head budgets +
  * var-len metadata.  Ada-SnapKV: given_capacity = NULL, M >= min(S-w, H*base); writes head_capacity, head_lens, cu_klen.

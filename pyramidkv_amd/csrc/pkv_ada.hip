@@ -132,6 +132,12 @@ __global__ __launch_bounds__(256) void ada_stats_kernel(BudgetParams p, AdaWs ws
   } else if (tid == 0) {
     ws.ratio[h] = 1.0f;
   }
+  if (p.adaptive_out) {   // head-sharded Ada-SnapKV: only the head's ADAPTIVE list (:711) is wanted - it is what the ranks exchange
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.adaptive_out) + (int64_t)h * p.L;
+    for (int i = tid; i < p.L; i += 256)
+      out[i] = p.normalize ? Elem<T>::from_f32(Elem<T>::to_f32(v[i]) * ratio) : v[i];
+    return;
+  }
   ws.cum_hi[h * 256 + tid] = count_ge<T>(v, p.L, ratio, p.normalize, (uint32_t)tid << 8);
 }
 
@@ -274,6 +280,7 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_stats, dim3(p.H), dim3(256), lds, st, p, ws);
+  if (p.adaptive_out) return hipGetLastError();
   hipLaunchKernelGGL(k_lo, dim3(p.H), dim3(256), lds, st, p, ws);
   hipLaunchKernelGGL(ada_final_kernel, dim3(1), dim3(256), 0, st, p, ws, omf, p.window, p.head_lens_out, p.cu_klen_out,
                      p.cu_headlens_out);

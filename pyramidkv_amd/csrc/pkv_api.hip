@@ -454,7 +454,7 @@ int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, 
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);     // int(base_capacity * floor_ratio) (:632)
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr;
   bp.window = 0; bp.head_lens_out = nullptr; bp.cu_klen_out = nullptr; bp.cu_headlens_out = nullptr;
-  bp.host_mirror = nullptr; bp.host_seq = 0;
+  bp.host_mirror = nullptr; bp.host_seq = 0; bp.adaptive_out = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(dtype, bp, st);
@@ -481,7 +481,29 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr;
   bp.window = window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = nullptr;
-  bp.host_mirror = nullptr; bp.host_seq = 0;
+  bp.host_mirror = nullptr; bp.host_seq = 0; bp.adaptive_out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(PKV_K_BUDGET, st);
+  hipError_t e = launch_budget(dtype, bp, st);
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t M, const void* scores, int64_t scores_stride,
+                           const int32_t* top_idx, int64_t idx_stride, int32_t base_capacity, int32_t normalize,
+                           void* lists_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (!scores || !top_idx || !lists_out || !ws) return PKV_ERR_NULL;
+  if (H < 1 || L < 1 || M < 1 || M > L || base_capacity < 1 || base_capacity > M) return PKV_ERR_SHAPE;
+  if (scores_stride < L || idx_stride < M) return PKV_ERR_SHAPE;
+  if (M > 65536) return PKV_ERR_UNSUPPORTED;
+  if (ws_bytes < 1024 + (size_t)2 * H * 256 * 4) return PKV_ERR_WORKSPACE;
+  BudgetParams bp;
+  bp.sorted_val = nullptr; bp.sorted_idx = top_idx; bp.idx_stride = idx_stride; bp.scores = scores; bp.scores_stride = scores_stride;
+  bp.Lrow = L; bp.H = H; bp.L = M; bp.base = base_capacity;
+  bp.one_minus_floor = 1.0f; bp.floor_capacity = 0;
+  bp.normalize = normalize; bp.head_capacity = nullptr; bp.ws = ws; bp.list_ws = nullptr;
+  bp.window = 0; bp.head_lens_out = nullptr; bp.cu_klen_out = nullptr; bp.cu_headlens_out = nullptr;
+  bp.host_mirror = nullptr; bp.host_seq = 0; bp.adaptive_out = lists_out;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(dtype, bp, st);
@@ -526,7 +548,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = w + W.off_ada; bp.list_ws = w + W.off_ada_list;
   bp.window = d->window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
-  bp.host_mirror = host_mirror; bp.host_seq = host_seq;
+  bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.adaptive_out = nullptr;
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(d->dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);

@@ -128,6 +128,7 @@ struct BudgetParams {
   int32_t* head_lens_out;    // [H] or null
   int32_t* cu_klen_out;      // [H+1] or null
   int32_t* cu_headlens_out;  // [H] inclusive prefix (:687) or null
+  void* adaptive_out;        // optional: dtype [H][L] - emit every head's adaptive list (:711) and stop (head-sharded exchange)
   int32_t* host_mirror;      // optional: device-visible PINNED HOST memory [H+1]; gets the capacities, then host_seq in [H]
   int32_t host_seq;
   void* list_ws;             // optional: H * roundup(L,8) * 2 bytes, 16-B aligned - the looked-up lists travel through it

@@ -109,3 +109,33 @@ class HeadShardedAdaKV:
         cap_local = cap_all[rank * Hl:(rank + 1) * Hl].contiguous()
         kf, vf, head_lens, cu_klen = self.gather_fn(key_states, value_states, sorted_idx, cap_local)
         return kf, vf, head_lens, cu_klen, cap_all
+
+
+def hip_head_sharded_adakv(num_heads_total: int, window_size: int, kernel_size: int, pooling: str, max_capacity_prompt: int,
+                           floor: float, normalize: bool, group: Optional[dist.ProcessGroup] = None) -> HeadShardedAdaKV:
+    """``HeadShardedAdaKV`` wired to the HIP stages (what a tensor-parallel host runs on every rank): local window scores ->
+    top-M indices of the local heads (M = min(L, H_total * base): the most one head can receive, so truncated lists decide
+    the global budget exactly) -> local ADAPTIVE lists (:709-711; the ratio needs the rank's own rows only) -> ONE
+    all-gather of those lists -> the budget of all heads on every rank (normalisation already applied) -> flat gather of
+    the local heads."""
+    from . import ops, config as _cfg
+    base = max_capacity_prompt - window_size
+
+    def score_sort(q, k):
+        s = ops.score_window(q, k, window_size, pooling, kernel_size, reduce="mean", scale_mode=_cfg.scale_mode,
+                             kv_group=q.shape[1] // k.shape[1])[0]
+        M = min(s.shape[-1], num_heads_total * base)
+        top_idx = ops.topk(s, M)
+        return top_idx, ops.ada_adaptive_lists(s, top_idx, base, bool(normalize))
+
+    def budget(all_lists):
+        return ops.ada_budget(all_lists, base, floor, False)
+
+    def gather(k, v, top_idx, cap_local):
+        head_lens, cu = ops.ada_metadata(cap_local, window_size)
+        caps = cap_local.tolist()
+        kf, vf = ops.gather_flat(k, v, top_idx, cap_local, cu, window_size, sum(caps) + len(caps) * window_size,
+                                 max_cap=max(caps), kv_group=top_idx.shape[0] // k.shape[1])
+        return kf, vf, head_lens, cu
+
+    return HeadShardedAdaKV(score_sort, budget, gather, group)

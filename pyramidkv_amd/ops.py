@@ -238,6 +238,23 @@ def ada_budget_topm(scores: torch.Tensor, top_idx: torch.Tensor, base_capacity: 
     return (cap, head_lens, cu) if window is not None else cap
 
 
+def ada_adaptive_lists(scores: torch.Tensor, top_idx: torch.Tensor, base_capacity: int, normalize: bool) -> torch.Tensor:
+    """pyramidkv_utils.py:709-711 for a head shard: scores [Hl,L], top_idx int32 [Hl,M] -> the adaptive lists [Hl,M] (model
+    dtype) the ranks of the head-sharded Ada-SnapKV exchange."""
+    _require_gpu(scores, top_idx)
+    Hl, L = scores.shape
+    M = top_idx.shape[1]
+    out = torch.empty(Hl, M, dtype=scores.dtype, device=scores.device)
+    nb = 1024 + 2 * Hl * 256 * 4
+    with torch.cuda.device(scores.device):
+        ws = workspace(nb, scores.device)
+        N.check(N.lib.pkv_ada_adaptive_lists(N.dtype_code(scores.dtype), Hl, L, M, scores.data_ptr(), scores.stride(0),
+                                             top_idx.data_ptr(), top_idx.stride(0), base_capacity, 1 if normalize else 0,
+                                             out.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr()),
+                "pkv_ada_adaptive_lists")
+    return out
+
+
 def ada_select(q, k, window: int, pooling, kernel_size: int, M: int, base_capacity: int = 0, floor_ratio: float = 0.0,
                normalize: bool = False, given_capacity: Optional[torch.Tensor] = None, scale_mode: str = "div",
                kv_group: int = 1, host_mirror: Optional[torch.Tensor] = None, host_seq: int = 0):
