@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="0 = one sequence per GPU (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--policy", default="pyramidkv", choices=["pyramidkv", "snapkv"])
+    ap.add_argument("--allgather", default="prefill", choices=["prefill", "layer"],
+                    help="multi-GPU exchange of the selected indices: one all-gather per prefill (all 32 layers) or one per layer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip grid / gqa / gpu_eager_baseline / strong leg")
     ap.add_argument("--cpu-layers", type=int, default=32, help="layer-calls per CPU-baseline pass (32 = the whole step)")
@@ -129,19 +131,26 @@ def main():
         torch.cuda.synchronize()
 
     def timed_leg(B, steps, warmup, sets):
+        xch = pdist.PrefillIndexExchange(ks, B, Hl, dev, force=collective) if (collective and a.allgather == "prefill") else None
+
         def one_step():
-            # the one exchange step of the path (indices, KBs) is issued asynchronously: layer i+1's update_kv does not
-            # depend on layer i's gathered indices, so the latency-bound collective overlaps with it; at most two are
-            # in flight and all are waited for (on the stream) before the step ends
+            # The one exchange step of the path: the selected indices (KBs).  No layer's update_kv depends on another layer's
+            # gathered indices, so (default) all 32 layers write into one buffer that is all-gathered ONCE per prefill;
+            # "--allgather layer" issues one asynchronous collective per layer instead (at most two in flight).
             outs, pending = None, []
             for layer in range(NUM_LAYERS):
                 q, k, v = sets[layer % len(sets)]
-                kc, vc, idx = P.ops.compress(q, k, v, W, ks[layer], "maxpool", 7, return_indices=True)
-                if collective:
-                    pending.append(pdist.allgather_indices_async(idx, force=True))
-                    if len(pending) > 2:
-                        idx = pending.pop(0).wait()
+                if xch is not None:
+                    kc, vc, idx = P.ops.compress(q, k, v, W, ks[layer], "maxpool", 7, idx_out=xch.slot(layer))
+                else:
+                    kc, vc, idx = P.ops.compress(q, k, v, W, ks[layer], "maxpool", 7, return_indices=True)
+                    if collective:
+                        pending.append(pdist.allgather_indices_async(idx, force=True))
+                        if len(pending) > 2:
+                            idx = pending.pop(0).wait()
                 outs = (kc, vc, idx)
+            if xch is not None:
+                outs = (outs[0], outs[1], xch.views(xch.gather_async())[-1])
             for h in pending:
                 outs = (outs[0], outs[1], h.wait())
             return outs
@@ -219,7 +228,7 @@ def main():
         "config": {"workload": "%s budget=%d window=8 maxpool7, 32 layer-calls/step, [B=%d,H=%d,S=%d,D=128] %s"
                                % (a.policy, cap, B, H, S, a.dtype),
                    "global_batch": B, "seq_len": S, "heads_per_gpu": Hl,
-                   "parallelism": ("head-shard x%d + 1 RCCL all-gather(indices)/layer" % world) if collective else "single GPU",
+                   "parallelism": ("head-shard x%d + 1 all-gather(indices) per %s" % (world, a.allgather)) if collective else "single GPU",
                    "collective_backend": (backend if collective else None)},
         "roofline": kernels.get("logits"),
         "roofline_kernels": kernels,

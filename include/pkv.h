@@ -120,6 +120,22 @@ int pkv_compress(const pkv_desc* d, const void* q, const void* k, const void* v,
 int pkv_compress_h2o(const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
                      void* v_out, int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream);
 
+/* Selection only: the front half of pkv_compress / pkv_compress_h2o (score -> top-k), idx_out int32 [B*H][d->topk].
+ * What a caller needs when something other than the plain gather follows (the merge below).  ws: pkv_workspace_bytes(d). */
+int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int32_t* idx_out, void* ws, size_t ws_bytes,
+               pkv_stream_t stream);
+
+/* LOOK-M pivot merge (pyramidkv_utils.py:119-170 merge_kv(..., merge="pivot"), called from :242,:274,:338,:566,:611 when the
+ * cluster's `merge` is set) instead of the plain gather: every position NO (batch, head) selected - the window positions
+ * included (:128-133) - is merged into its most cosine-similar kept key (first maximum, :150-151) as (x + pivot)/2, and the
+ * kept rows become the scatter-mean of what reached them (:158-162).  As in the reference k_out is ordered
+ * [window, selected] (:146) and v_out [selected, window] (:148), and the value merge uses the key order's pivot numbers.
+ * idx: int32 [B*H][idx_stride] (d->topk = k entries per row, from pkv_select / pkv_topk).  Outputs [B,H,k+w,D] contiguous.
+ * ws: pkv_merge_workspace_bytes(d), 16-B aligned.  Rounding points: oracle/pkv_oracle.py merge_kv_explicit. */
+size_t pkv_merge_workspace_bytes(const pkv_desc* d);
+int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx, int64_t idx_stride,
+                      void* k_out, void* v_out, void* ws, size_t ws_bytes, pkv_stream_t stream);
+
 /* ---- Ada-SnapKV / HeadKV (pyramidkv_utils.py:674-757, :808-878): flat var-len output ---- */
 
 /* Per-row full descending sort (:706 attn_score.sort(descending=True)), ties index-ascending.

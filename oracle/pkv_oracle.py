@@ -33,7 +33,7 @@ import torch.nn.functional as F
 
 __all__ = [
     "pyramid_budget", "window_logits", "window_scores", "h2o_scores", "h2o_scores_blocked",
-    "pool_scores", "topk_canonical", "topk_reference", "gather_compact",
+    "pool_scores", "topk_canonical", "topk_reference", "gather_compact", "merge_kv", "merge_kv_explicit",
     "snapkv_update_kv", "pyramidkv_update_kv", "h2o_update_kv", "streamingllm_update_kv",
     "adakv_update_kv", "headkv_update_kv", "AdaMeta", "equivalent_selection",
 ]
@@ -194,15 +194,108 @@ def gather_compact(key_states, value_states, indices: torch.Tensor, window_size:
             torch.cat([v_past, value_states[:, :, -w:, :]], dim=2))
 
 
+# --------------------------------------------------------------------------- merge (LOOK-M pivot merge)
+def merge_kv(key_states, value_states, indices: torch.Tensor, window_size: int, merge: str):
+    """pyramidkv_utils.py:119-170, op for op (``indices`` int64 [B,H,k], un-expanded).  The quirks are the spec:
+      * a position is "dropped" iff NO (batch, head) selected it (``isin`` over the flattened indices of all heads, :128-133),
+        and the window positions count as dropped too (``arange(k_len)``, :128) - they merge onto themselves;
+      * keys come back ordered [window, selected] (:146) but values [selected, window] (:148), and the value merge uses the
+        KEY order's target numbers (:162) on the VALUE order's rows;
+      * every dropped key is averaged with its most similar kept key, (k_drop + k_pivot)/2 (:160), and the results are
+        scatter-reduced (mean, include_self) onto the pivots (:161)."""
+    if merge != "pivot":
+        raise ValueError('Merge method not supported')                                            # :164
+    bsz, num_heads, k_len, head_dim = key_states.shape
+    idx = indices.to(torch.int64).unsqueeze(-1).expand(-1, -1, -1, head_dim)
+    selected_keys = key_states.gather(dim=2, index=idx)                                           # :125
+    selected_values = value_states.gather(dim=2, index=idx)
+    all_indices = torch.arange(k_len, device=key_states.device).unsqueeze(0).unsqueeze(0).expand(bsz, num_heads, k_len)
+    all_flat = all_indices.flatten()
+    is_selected = torch.isin(all_flat, idx.flatten())                                             # :131
+    drop_flat = all_flat[~is_selected]
+    drop_len = drop_flat.shape[0] // (bsz * num_heads)
+    drop_indices = drop_flat.reshape(bsz, num_heads, drop_len).unsqueeze(-1).expand(-1, -1, -1, head_dim)
+    drop_keys = key_states.gather(dim=2, index=drop_indices)                                      # :137
+    drop_values = value_states.gather(dim=2, index=drop_indices)
+    recent_keys = key_states[:, :, -window_size:, :]
+    k_hh_recent = torch.cat([recent_keys, selected_keys], dim=2)                                  # :146
+    v_hh_recent = torch.cat([selected_values, value_states[:, :, -window_size:, :]], dim=2)       # :148
+    similarity = (drop_keys / torch.norm(drop_keys, dim=-1).unsqueeze(-1).repeat(1, 1, 1, head_dim)) @ \
+        ((k_hh_recent / (torch.norm(k_hh_recent, dim=-1).unsqueeze(-1).repeat(1, 1, 1, head_dim))).transpose(-1, -2))   # :150
+    _, max_indices = similarity.max(dim=-1)                                                       # :151
+    merged_indices = max_indices.unsqueeze(-1).repeat(1, 1, 1, head_dim)                          # :156
+    k_hh_selected = torch.gather(input=k_hh_recent, dim=2, index=merged_indices)
+    k_hh_merged = (drop_keys + k_hh_selected) / 2                                                 # :158
+    k_out = torch.scatter_reduce(input=k_hh_recent, dim=2, index=merged_indices, src=k_hh_merged, reduce='mean',
+                                 include_self=True)                                               # :159
+    v_hh_selected = torch.gather(input=v_hh_recent, dim=2, index=merged_indices)
+    v_hh_merged = (drop_values + v_hh_selected) / 2
+    v_out = torch.scatter_reduce(input=v_hh_recent, dim=2, index=merged_indices, src=v_hh_merged, reduce='mean',
+                                 include_self=True)                                               # :162
+    return k_out, v_out
+
+
+def merge_kv_explicit(key_states, value_states, indices: torch.Tensor, window_size: int):
+    """The arithmetic of ``merge_kv`` spelled out element by element - the specification the HIP kernels implement
+    (checked against the ATen form above in tests/test_oracle_merge.py; small cases only, Python loops):
+      norm      n = dtype(sqrt(sum x^2))                       (torch.norm, fp32 accumulate, one rounding)
+      cosine    sim = dtype(dot(dtype(x / n_x), dtype(t / n_t)))  (fp32 accumulate), pivot = FIRST maximum
+      merged    m = dtype(dtype(x + t_pivot) / 2)
+      scatter   out_j = dtype( dtype(t_j + sum_i m_i  [fp32, ascending i])  /  dtype(1 + n_j) )
+    where dtype(.) is one round-to-nearest-even to the model dtype.  Note dtype(1 + n_j): above 256 (bf16) / 2048 (fp16)
+    merged rows the divisor itself is rounded."""
+    B, H, S, D = key_states.shape
+    k, w, tdt = indices.shape[-1], window_size, key_states.dtype
+
+    def rnd(x):
+        return x.to(tdt).float()
+
+    union = set(indices.flatten().tolist())
+    drop = [p for p in range(S) if p not in union]
+    ko = torch.empty(B, H, k + w, D, dtype=tdt)
+    vo = torch.empty(B, H, k + w, D, dtype=tdt)
+    for b in range(B):
+        for h in range(H):
+            Kf, Vf = key_states[b, h].float(), value_states[b, h].float()
+            sel = indices[b, h].to(torch.int64)
+            tgt_k = torch.cat([Kf[S - w:], Kf[sel]], 0)             # [window, selected]
+            tgt_v = torch.cat([Vf[sel], Vf[S - w:]], 0)             # [selected, window]
+
+            def unit(X):
+                n = rnd(torch.sqrt((X * X).sum(-1)))
+                return rnd(X / n[:, None])
+
+            sim = rnd(unit(Kf[drop]) @ unit(tgt_k).T)
+            pivot = (sim == sim.max(-1, keepdim=True).values).float().argmax(-1)   # first maximum
+            acc_k, acc_v, cnt = tgt_k.clone(), tgt_v.clone(), torch.ones(w + k)
+            for i, p in enumerate(drop):
+                j = int(pivot[i])
+                acc_k[j] = acc_k[j] + rnd(rnd(Kf[p] + tgt_k[j]) / 2)
+                acc_v[j] = acc_v[j] + rnd(rnd(Vf[p] + tgt_v[j]) / 2)
+                cnt[j] += 1
+            ko[b, h] = (rnd(acc_k) / rnd(cnt)[:, None]).to(tdt)
+            vo[b, h] = (rnd(acc_v) / rnd(cnt)[:, None]).to(tdt)
+    return ko, vo
+
+
 # --------------------------------------------------------------------------- policies
 def _select(scores, k, topk_mode):
     return topk_canonical(scores, k) if topk_mode == "canonical" else topk_reference(scores, k)
 
 
+def _finish(key_states, value_states, idx, window_size, merge, return_indices):
+    """:336-346 (and the identical tails of the other policies): merge_kv when ``merge`` is set, else gather + window tail."""
+    if merge is not None:
+        kc, vc = merge_kv(key_states, value_states, idx, window_size, merge)                       # :337-339
+    else:
+        kc, vc = gather_compact(key_states, value_states, idx, window_size)
+    return (kc, vc, idx) if return_indices else (kc, vc)
+
+
 def snapkv_update_kv(key_states, query_states, value_states, window_size, max_capacity_prompt,
                      kernel_size, pooling, topk_mode="canonical", scale_mode="div",
-                     return_indices=False):
-    """SnapKVCluster.update_kv, pyramidkv_utils.py:306-347 (merge=None)."""
+                     return_indices=False, merge=None):
+    """SnapKVCluster.update_kv, pyramidkv_utils.py:306-347."""
     assert key_states.shape[-2] == query_states.shape[-2]
     q_len = query_states.shape[-2]
     if q_len < max_capacity_prompt:                                           # :314
@@ -210,14 +303,13 @@ def snapkv_update_kv(key_states, query_states, value_states, window_size, max_ca
     s = window_scores(query_states, key_states, window_size, "sum", scale_mode)
     s = pool_scores(s, pooling, kernel_size)
     idx = _select(s, max_capacity_prompt - window_size, topk_mode)            # :334
-    kc, vc = gather_compact(key_states, value_states, idx, window_size)
-    return (kc, vc, idx) if return_indices else (kc, vc)
+    return _finish(key_states, value_states, idx, window_size, merge, return_indices)
 
 
 def pyramidkv_update_kv(key_states, query_states, value_states, window_size, max_capacity_prompt,
                         kernel_size, pooling, num_hidden_layers, layer_idx, beta=20,
-                        topk_mode="canonical", scale_mode="div", return_indices=False):
-    """PyramidKVCluster.update_kv, pyramidkv_utils.py:197-283 (merge=None)."""
+                        topk_mode="canonical", scale_mode="div", return_indices=False, merge=None):
+    """PyramidKVCluster.update_kv, pyramidkv_utils.py:197-283."""
     assert key_states.shape[-2] == query_states.shape[-2]
     q_len = query_states.shape[-2]
     branch, k = pyramid_budget(max_capacity_prompt, window_size, num_hidden_layers, layer_idx, q_len, beta)
@@ -226,13 +318,12 @@ def pyramidkv_update_kv(key_states, query_states, value_states, window_size, max
     s = window_scores(query_states, key_states, window_size, "sum", scale_mode)
     s = pool_scores(s, pooling, kernel_size)
     idx = _select(s, k, topk_mode)
-    kc, vc = gather_compact(key_states, value_states, idx, window_size)
-    return (kc, vc, idx) if return_indices else (kc, vc)
+    return _finish(key_states, value_states, idx, window_size, merge, return_indices)
 
 
 def h2o_update_kv(key_states, query_states, value_states, window_size, max_capacity_prompt,
-                  topk_mode="canonical", scale_mode="div", blocked=False, return_indices=False):
-    """H2OKVCluster.update_kv, pyramidkv_utils.py:533-575 (merge=None)."""
+                  topk_mode="canonical", scale_mode="div", blocked=False, return_indices=False, merge=None):
+    """H2OKVCluster.update_kv, pyramidkv_utils.py:533-575."""
     assert key_states.shape[-2] == query_states.shape[-2]
     q_len = query_states.shape[-2]
     if q_len < max_capacity_prompt:                                           # :541
@@ -240,12 +331,11 @@ def h2o_update_kv(key_states, query_states, value_states, window_size, max_capac
     fn = h2o_scores_blocked if blocked else h2o_scores
     s = fn(query_states, key_states, window_size, scale_mode=scale_mode)
     idx = _select(s, max_capacity_prompt - window_size, topk_mode)            # :562
-    kc, vc = gather_compact(key_states, value_states, idx, window_size)
-    return (kc, vc, idx) if return_indices else (kc, vc)
+    return _finish(key_states, value_states, idx, window_size, merge, return_indices)
 
 
 def streamingllm_update_kv(key_states, query_states, value_states, window_size, max_capacity_prompt,
-                           return_indices=False):
+                           return_indices=False, merge=None):
     """StreamingLLMKVCluster.update_kv, pyramidkv_utils.py:595-620: sinks 0..cap-w-1 + last w."""
     assert key_states.shape[-2] == query_states.shape[-2]
     bsz, num_heads, q_len, head_dim = query_states.shape
@@ -253,8 +343,7 @@ def streamingllm_update_kv(key_states, query_states, value_states, window_size, 
         return (key_states, value_states, None) if return_indices else (key_states, value_states)
     idx = torch.arange(max_capacity_prompt - window_size, dtype=torch.int64, device=key_states.device)
     idx = idx[None, None, :].repeat(bsz, num_heads, 1)                        # :607-608
-    kc, vc = gather_compact(key_states, value_states, idx, window_size)
-    return (kc, vc, idx) if return_indices else (kc, vc)
+    return _finish(key_states, value_states, idx, window_size, merge, return_indices)
 
 
 @dataclass

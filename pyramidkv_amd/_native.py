@@ -58,6 +58,9 @@ def _load():
         "pkv_gather_streaming": (C.c_int, [dp, vp, vp, vp, vp, vp]),
         "pkv_compress": (C.c_int, [dp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "pkv_compress_h2o": (C.c_int, [dp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "pkv_select": (C.c_int, [dp, vp, vp, i32, vp, vp, sz, vp]),
+        "pkv_merge_workspace_bytes": (sz, [dp]),
+        "pkv_merge_compact": (C.c_int, [dp, vp, vp, vp, i64, vp, vp, vp, sz, vp]),
         "pkv_sort_rows": (C.c_int, [i32, i32, i32, vp, i64, vp, vp, vp]),
         "pkv_ada_budget": (C.c_int, [i32, i32, i32, vp, i32, C.c_double, i32, vp, vp, sz, vp]),
         "pkv_ada_budget_topm": (C.c_int, [i32, i32, i32, i32, vp, i64, vp, i64, i32, C.c_double, i32, i32, vp, vp, vp, vp, sz, vp]),

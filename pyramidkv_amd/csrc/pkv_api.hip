@@ -423,6 +423,68 @@ int pkv_compress_h2o(const pkv_desc* d, const void* q, const void* k, const void
   return compress_common(true, d, q, k, v, k_out, v_out, idx_out, ws, ws_bytes, stream);
 }
 
+// ---- selection only (score -> top-k), the front half of pkv_compress: what the merge path needs ----
+int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int32_t* idx_out, void* ws, size_t ws_bytes,
+               pkv_stream_t stream) {
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  if (!q || !k || !idx_out || !ws) return PKV_ERR_NULL;
+  if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
+  WsLayout L = ws_layout(d);
+  if (ws_bytes < (h2o ? L.total : L.off_rowstat)) return PKV_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* w = static_cast<char*>(ws);
+  void* scores = w + L.off_scores;
+  const bool cm = !h2o && env_int("PKV_TOPK_CMAX", 1) != 0;
+  rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
+  if (rc) return rc;
+  return do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx_out, d->topk, st,
+                 cm ? w + L.off_cmax : nullptr, L.Lp / 8, w + L.off_tk, L.tk_bytes);
+}
+
+namespace {
+struct MergeWs { size_t off_mask, off_n, off_drop, off_pivot, off_tn, total; int ntp; };
+MergeWs merge_ws(const pkv_desc* d) {
+  MergeWs m;
+  size_t o = 0;
+  m.ntp = (int)align_up((size_t)(d->topk + d->window), 8);
+  m.off_mask = o;  o = align_up(o + (size_t)d->S, 256);
+  m.off_n = o;     o = align_up(o + 4, 256);
+  m.off_drop = o;  o = align_up(o + (size_t)d->S * 4, 256);
+  m.off_pivot = o; o = align_up(o + (size_t)d->B * d->H * d->S * 4, 256);
+  m.off_tn = o;    o = align_up(o + (size_t)d->B * d->H * m.ntp * 128 * 2, 256);
+  m.total = o;
+  return m;
+}
+}  // namespace
+
+size_t pkv_merge_workspace_bytes(const pkv_desc* d) {
+  if (!d || d->S < 2 || d->window < 1 || d->window >= d->S || d->B < 1 || d->H < 1 || d->topk < 1) return 0;
+  return merge_ws(d).total;
+}
+
+int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx, int64_t idx_stride,
+                      void* k_out, void* v_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  int rc = check_desc(d, true, false);
+  if (rc) return rc;
+  if (!k || !v || !idx || !k_out || !v_out || !ws) return PKV_ERR_NULL;
+  if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out) || misaligned(ws)) return PKV_ERR_ALIGN;
+  if (idx_stride < d->topk) return PKV_ERR_SHAPE;
+  MergeWs m = merge_ws(d);
+  if (ws_bytes < m.total) return PKV_ERR_WORKSPACE;
+  char* w = static_cast<char*>(ws);
+  MergeParams p;
+  p.kptr = k; p.vptr = v; p.idx = idx; p.idx_stride = idx_stride; p.k_out = k_out; p.v_out = v_out;
+  p.B = d->B; p.H = d->H; p.S = d->S; p.w = d->window; p.k = d->topk; p.G = d->kv_group;
+  p.ks_b = d->k_stride[0]; p.ks_h = d->k_stride[1]; p.ks_s = d->k_stride[2];
+  p.vs_b = d->v_stride[0]; p.vs_h = d->v_stride[1]; p.vs_s = d->v_stride[2];
+  p.mask = reinterpret_cast<uint8_t*>(w + m.off_mask); p.ndrop = reinterpret_cast<int32_t*>(w + m.off_n);
+  p.drop = reinterpret_cast<int32_t*>(w + m.off_drop); p.pivot = reinterpret_cast<int32_t*>(w + m.off_pivot);
+  p.tn = w + m.off_tn; p.ntp = m.ntp;
+  hipError_t e = launch_merge(d->dtype, p, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
 int pkv_sort_rows(int32_t dtype, int32_t rows, int32_t L, const void* scores, int64_t scores_stride,
                   int32_t* sorted_idx, void* sorted_val, pkv_stream_t stream) {
   if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;

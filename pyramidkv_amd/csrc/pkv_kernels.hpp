@@ -135,6 +135,24 @@ struct BudgetParams {
   void* ws;                  // 1024 B ratios + 2 * H*256 int32
 };
 
+struct MergeParams {         // LOOK-M pivot merge (pkv_merge.hip)
+  const void* kptr;
+  const void* vptr;
+  const int32_t* idx;        // [B*H][idx_stride] selected past tokens (top-k order)
+  int64_t idx_stride;
+  void* k_out;               // [B,H,k+w,D]  rows ordered [window, selected]
+  void* v_out;               // [B,H,k+w,D]  rows ordered [selected, window]
+  int B, H, S, w, k, G;
+  int64_t ks_b, ks_h, ks_s;
+  int64_t vs_b, vs_h, vs_s;
+  uint8_t* mask;             // [S] 1 = selected by some (b,h)
+  int32_t* ndrop;            // number of dropped positions
+  int32_t* drop;             // [S] dropped positions, ascending
+  int32_t* pivot;            // [B*H][S] kept-row number (KEY order) every dropped row merges into
+  void* tn;                  // [B*H][ntp][128] unit-norm kept keys
+  int ntp;
+};
+
 struct FlattenParams {
   const void* cache;
   const void* state;
@@ -173,6 +191,7 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
 hipError_t launch_ada_metadata(int H, int w, const int32_t* cap, int32_t* head_lens, int32_t* cu_klen, hipStream_t st,
                                int32_t* cu_headlens = nullptr);
 hipError_t launch_flatten(const FlattenParams& p, hipStream_t st);
+hipError_t launch_merge(int dtype, const MergeParams& p, hipStream_t st);
 hipError_t launch_debug_exp(const float* in, float* out, int64_t n, hipStream_t st);
 hipError_t launch_debug_round(int dtype, const float* in, uint16_t* out, int64_t n, hipStream_t st);
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st);

@@ -10,24 +10,9 @@
 // round trip through L2/MALL between the two kernels.
 #include "pkv_common.hpp"
 #include "pkv_kernels.hpp"
+#include "pkv_mfma.hpp"
 
 namespace pkv {
-
-typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
-typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8_t;
-
-template <typename T> struct Mfma;
-template <> struct Mfma<BF16> {
-  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-  }
-};
-template <> struct Mfma<F16> {
-  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-  }
-};
 
 // ------------------------------------------------------------------------------------------------
 // logits_kernel: one workgroup = 4*KPW keys of one (batch, kv-head group); 4 waves x KPW keys.

@@ -165,8 +165,9 @@ def gather_streaming(k, v, n_sink: int, window: int):
 
 
 def compress(q, k, v, window: int, topk_k: int, pooling, kernel_size: int, scale_mode: str = "div",
-             kv_group: int = 1, h2o: bool = False, return_indices: bool = False):
-    """Fused score -> top-k -> gather (pyramidkv_utils.py:317-346 / :544-575): one C call."""
+             kv_group: int = 1, h2o: bool = False, return_indices: bool = False, idx_out: Optional[torch.Tensor] = None):
+    """Fused score -> top-k -> gather (pyramidkv_utils.py:317-346 / :544-575): one C call.  ``idx_out`` (contiguous int32
+    [B,H,k], e.g. a slice of a per-prefill buffer that is all-gathered once) receives the indices instead of a new tensor."""
     _require_gpu(q, k, v)
     q, k, v = _rowmajor(q), _rowmajor(k), _rowmajor(v)
     B, H, S, D = q.shape
@@ -175,12 +176,50 @@ def compress(q, k, v, window: int, topk_k: int, pooling, kernel_size: int, scale
         ws = workspace(N.lib.pkv_workspace_bytes(d), k.device)
         ko = torch.empty(B, H, topk_k + window, D, dtype=k.dtype, device=k.device)
         vo = torch.empty_like(ko)
-        idx = torch.empty(B, H, topk_k, dtype=torch.int32, device=k.device) if return_indices else None
+        if idx_out is not None:
+            assert idx_out.dtype == torch.int32 and idx_out.is_contiguous() and idx_out.numel() == B * H * topk_k
+            idx, return_indices = idx_out, True
+        else:
+            idx = torch.empty(B, H, topk_k, dtype=torch.int32, device=k.device) if return_indices else None
         fn = N.lib.pkv_compress_h2o if h2o else N.lib.pkv_compress
         N.check(fn(d, q.data_ptr(), k.data_ptr(), v.data_ptr(), ko.data_ptr(), vo.data_ptr(),
                    idx.data_ptr() if idx is not None else None, ws.data_ptr(), ws.numel(), N.stream_ptr()),
                 "pkv_compress")
     return (ko, vo, idx) if return_indices else (ko, vo)
+
+
+def select(q, k, window: int, topk_k: int, pooling, kernel_size: int, scale_mode: str = "div", kv_group: int = 1,
+           h2o: bool = False) -> torch.Tensor:
+    """Score -> top-k only (the front half of ``compress``): int32 indices [B,H,k] in (value desc, index asc) order."""
+    _require_gpu(q, k)
+    q, k = _rowmajor(q), _rowmajor(k)
+    B, H = q.shape[0], q.shape[1]
+    with torch.cuda.device(k.device):
+        d = make_desc(q, k, None, window, None if h2o else pooling, kernel_size, "sum", scale_mode, topk_k, kv_group)
+        ws = workspace(N.lib.pkv_workspace_bytes(d), k.device)
+        idx = torch.empty(B, H, topk_k, dtype=torch.int32, device=k.device)
+        N.check(N.lib.pkv_select(d, q.data_ptr(), k.data_ptr(), 1 if h2o else 0, idx.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 N.stream_ptr()), "pkv_select")
+    return idx
+
+
+def merge_compact(k, v, idx: torch.Tensor, window: int, kv_group: int = 1):
+    """pyramidkv_utils.py:119-170 merge_kv(..., "pivot"): idx int32 [B,H,n] -> (K_m [B,H,n+w,D] ordered [window, selected],
+    V_m [B,H,n+w,D] ordered [selected, window]) - the reference's own orders."""
+    _require_gpu(k, v, idx)
+    k, v = _rowmajor(k), _rowmajor(v)
+    B, H, n = idx.shape
+    idx = idx.to(torch.int32).contiguous()
+    D = k.shape[-1]
+    with torch.cuda.device(k.device):
+        d = make_desc(None, k, v, window, topk=n, kv_group=kv_group, num_heads=H)
+        ko = torch.empty(B, H, n + window, D, dtype=k.dtype, device=k.device)
+        vo = torch.empty_like(ko)
+        nb = N.lib.pkv_merge_workspace_bytes(d)
+        ws = torch.empty(nb, dtype=torch.uint8, device=k.device)
+        N.check(N.lib.pkv_merge_compact(d, k.data_ptr(), v.data_ptr(), idx.data_ptr(), n, ko.data_ptr(), vo.data_ptr(),
+                                        ws.data_ptr(), nb, N.stream_ptr()), "pkv_merge_compact")
+    return ko, vo
 
 
 def sort_rows(scores: torch.Tensor, want_values: bool = True):

@@ -8,7 +8,9 @@ libpkv's HIP kernels through the C ABI (``include/pkv.h``); nothing is computed 
 
 Differences from the reference, all deliberate:
   * no per-call ``print`` (pyramidkv_utils.py:217,312,539,601 write to stdout on every layer);
-  * ``merge`` (LOOK-M pivot merge, :119-170) is out of scope: a non-None ``merge`` raises;
+  * ``merge="pivot"`` (LOOK-M pivot merge, :119-170) runs in HIP kernels (libpkv ``pkv_merge_compact``) with the
+    reference's own output orders (keys [window, selected], values [selected, window]); any other value raises
+    ``ValueError('Merge method not supported')`` as :164 does;
   * top-k tie order is pinned to (value desc, index asc) - see DESIGN.md;
   * tensors must live on a HIP device (no CPU path).
 """
@@ -22,9 +24,8 @@ from .cache import DynamicCacheSplitHeadFlatten  # noqa: F401  (llama_model.py:2
 
 
 def _check_merge(merge):
-    if merge is not None:
-        raise NotImplementedError("merge (LOOK-M pivot merge, reference pyramidkv_utils.py:119-170) is out of scope "
-                                  "of pyramidkv_amd; pass merge=None")
+    if merge is not None and merge != "pivot":
+        raise ValueError('Merge method not supported')                               # :164
 
 
 def _kv_group(num_key_value_groups, num_heads) -> int:
@@ -71,6 +72,12 @@ class _WindowPolicy:
 
     def _compress(self, key_states, query_states, value_states, k, num_key_value_groups, h2o=False):
         gu = _unexpanded_group(key_states, query_states)
+        if getattr(self, "merge", None) is not None:                                 # :336-339: merge_kv instead of the gather
+            g = gu if gu > 1 else _kv_group(num_key_value_groups, query_states.shape[1])
+            ks, vs = (key_states, value_states) if gu > 1 else (_dedup_view(key_states, g), _dedup_view(value_states, g))
+            idx = ops.select(query_states, ks, self.window_size, k, self.pooling, self.kernel_size,
+                             scale_mode=_cfg.scale_mode, kv_group=g, h2o=h2o)
+            return ops.merge_compact(ks, vs, idx, self.window_size, kv_group=g)
         if gu > 1:
             return ops.compress(query_states, key_states, value_states, self.window_size, k, self.pooling,
                                 self.kernel_size, scale_mode=_cfg.scale_mode, kv_group=gu, h2o=h2o)
@@ -217,6 +224,11 @@ class StreamingLLMKVCluster:
         if q_len < self.max_capacity_prompt:                                        # :603
             return _repeat_kv(key_states, g), _repeat_kv(value_states, g)
         _check_merge(self.merge)
+        if self.merge is not None:                                                   # :609-613
+            bsz, num_heads = query_states.shape[0], query_states.shape[1]
+            n = self.max_capacity_prompt - self.window_size
+            idx = torch.arange(n, dtype=torch.int32, device=key_states.device)[None, None, :].expand(bsz, num_heads, n)
+            return ops.merge_compact(key_states, value_states, idx.contiguous(), self.window_size, kv_group=g)
         kc, vc = ops.gather_streaming(key_states, value_states, self.max_capacity_prompt - self.window_size,
                                       self.window_size)
         return _repeat_kv(kc, g), _repeat_kv(vc, g)       # every head of a group keeps the same tokens

@@ -93,23 +93,37 @@ case(policy="headkv", dtype="bf16", kind="gauss", B=1, H=4, S=512, w=8, cap=64, 
      head_capacity=[[10, 70, 56, 33]], layer=0)
 
 
+# LOOK-M pivot merge (merge_kv, :119-170) behind every dense policy.  Appended at the END so that the numbering of the
+# earlier fixtures never moves.  tie_free = planted heavy hitters, kernel 1: the selection is fully determined, so the
+# merged K/V of the REAL reference are comparable bit for bit with any backend.
+for dt in ("bf16", "fp16"):
+    case(policy="snapkv", dtype=dt, kind="planted", B=1, H=2, S=2048, w=8, cap=40, ks=1, pool="avgpool", seed=191, tie_free=True,
+         merge="pivot")
+case(policy="pyramidkv", dtype="bf16", kind="planted", B=1, H=2, S=2048, w=8, cap=24, ks=1, pool="maxpool", seed=192,
+     layers=32, layer=5, tie_free=True, merge="pivot")
+case(policy="snapkv", dtype="bf16", kind="gauss", B=2, H=2, S=512, w=8, cap=64, ks=7, pool="maxpool", seed=193, merge="pivot")
+case(policy="snapkv", dtype="fp16", kind="lattice", B=1, H=4, S=384, w=32, cap=96, ks=5, pool="avgpool", seed=194, merge="pivot")
+case(policy="h2o", dtype="bf16", kind="gauss", B=1, H=2, S=256, w=8, cap=48, ks=0, pool="none", seed=195, merge="pivot")
+case(policy="streamingllm", dtype="bf16", kind="gauss", B=2, H=2, S=256, w=60, cap=64, ks=0, pool="none", seed=196, merge="pivot")
+
+
 def run_case(c):
     q, k, v = make_qkv(c["B"], c["H"], c["S"], 128, c["dtype"], c["kind"], c["seed"])
     w, cap = c["w"], c["cap"]
     pol = c["policy"]
     meta = {}
     if pol == "snapkv":
-        cl = ref.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
+        cl = ref.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"], merge=c.get("merge"))
         kc, vc = quiet(cl.update_kv, k, q, v, None, 1)
     elif pol == "pyramidkv":
         cl = ref.PyramidKVCluster(num_hidden_layers=c["layers"], layer_idx=c["layer"], window_size=w,
-                                  max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"])
+                                  max_capacity_prompt=cap, kernel_size=c["ks"], pooling=c["pool"], merge=c.get("merge"))
         kc, vc = quiet(cl.update_kv, k, q, v, None, 1)
     elif pol == "h2o":
-        cl = ref.H2OKVCluster(window_size=w, max_capacity_prompt=cap)
+        cl = ref.H2OKVCluster(window_size=w, max_capacity_prompt=cap, merge=c.get("merge"))
         kc, vc = quiet(cl.update_kv, k, q, v, None, 1)
     elif pol == "streamingllm":
-        cl = ref.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap)
+        cl = ref.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap, merge=c.get("merge"))
         kc, vc = quiet(cl.update_kv, k, q, v, None, 1)
     elif pol in ("adakv", "headkv"):
         if pol == "adakv":
@@ -137,8 +151,8 @@ def run_case(c):
                 idx.append(recover_indices(k[:, h:h + 1, :-w], rows)[0, 0])
                 off += int(hl[h])
             out["idx_flat"] = np.concatenate(idx).astype(np.int32)
-    elif not passthrough:
-        out["idx"] = recover_indices(k[:, :, :-w], kc[:, :, :-w])
+    elif not passthrough and not c.get("merge"):
+        out["idx"] = recover_indices(k[:, :, :-w], kc[:, :, :-w])      # merged rows are no copies of source rows: no indices
     return out
 
 
@@ -161,13 +175,17 @@ def head_capacity_fixture():
 def main():
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     index = []
+    force = "--force" in sys.argv
     for i, c in enumerate(CASES):
-        name = f"{i:02d}_{c['policy']}_{c['dtype']}_{c['kind']}_S{c['S']}"
+        name = f"{i:02d}_{c['policy']}_{c['dtype']}_{c['kind']}_S{c['S']}" + ("_merge" if c.get("merge") else "")
+        index.append(dict(name=name, **c))
+        if os.path.exists(os.path.join(HERE, name + ".npz")) and not force:
+            continue                       # fixtures already committed stay byte-identical (re-create with --force)
         out = run_case(c)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-        index.append(dict(name=name, **c))
         print(name, {k: getattr(v, 'shape', v) for k, v in out.items() if k not in ('kc', 'vc')})
-    head_capacity_fixture()
+    if force or not os.path.exists(os.path.join(HERE, "headkv_capacity_llama3.npz")):
+        head_capacity_fixture()
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(dict(torch=torch.__version__, reference="Zefan-Cai/PyramidKV@2024-12-20",
                        cases=index), f, indent=1)

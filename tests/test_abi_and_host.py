@@ -88,8 +88,11 @@ def test_constructor_contract_and_errors(P):
     cl = P.SnapKVCluster(window_size=8, max_capacity_prompt=64, pooling="medianpool")
     with pytest.raises(ValueError, match="Pooling method not supported"):   # reference :333
         cl.update_kv(k, q, v, None, 1)
+    cl = P.SnapKVCluster(window_size=8, max_capacity_prompt=64, pooling="maxpool", merge="average")
+    with pytest.raises(ValueError, match="Merge method not supported"):     # reference :164
+        cl.update_kv(k, q, v, None, 1)
     cl = P.SnapKVCluster(window_size=8, max_capacity_prompt=64, pooling="maxpool", merge="pivot")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback|HIP"):        # merge="pivot" is a HIP path too: never on CPU
         cl.update_kv(k, q, v, None, 1)
     cl = P.SnapKVCluster(window_size=8, max_capacity_prompt=64, pooling="maxpool")
     with pytest.raises(AssertionError):

@@ -110,3 +110,30 @@ def test_head_sharded_adakv_world2():
     ret = mgr.dict()
     mp.spawn(_ada_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _prefill_exchange_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyramidkv_amd import dist as pdist
+    B, H, ks = 2, 8, [11, 7, 3]
+    Hl = H // world
+    full = [torch.arange(B * H * k, dtype=torch.int32).view(B, H, k) * (i + 1) for i, k in enumerate(ks)]   # the unsharded truth
+    xch = pdist.PrefillIndexExchange(ks, B, Hl, "cpu")
+    for i in range(len(ks)):
+        xch.slot(i).copy_(full[i][:, rank * Hl:(rank + 1) * Hl])          # what ops.compress(idx_out=slot) writes on the GPU
+    got = xch.views(xch.gather_async())
+    ret[rank] = all(torch.equal(a, b) for a, b in zip(got, full)) and len(got) == len(ks)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_allgather_per_prefill_world2():
+    """PrefillIndexExchange: the selections of all layers travel in ONE all-gather; per-layer [B, H, k_l] views come back
+    in head-major (= rank) order."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_prefill_exchange_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)

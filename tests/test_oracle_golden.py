@@ -32,15 +32,16 @@ def _load(c):
 def _run(c, q, k, v, mode):
     pol, w, cap = c["policy"], c["w"], c["cap"]
     pool = None if c["pool"] == "none" else c["pool"]
+    mg = c.get("merge")
     if pol == "snapkv":
-        return O.snapkv_update_kv(k, q, v, w, cap, c["ks"], pool, topk_mode=mode, return_indices=True)
+        return O.snapkv_update_kv(k, q, v, w, cap, c["ks"], pool, topk_mode=mode, return_indices=True, merge=mg)
     if pol == "pyramidkv":
         return O.pyramidkv_update_kv(k, q, v, w, cap, c["ks"], pool, c["layers"], c["layer"],
-                                     topk_mode=mode, return_indices=True)
+                                     topk_mode=mode, return_indices=True, merge=mg)
     if pol == "h2o":
-        return O.h2o_update_kv(k, q, v, w, cap, topk_mode=mode, return_indices=True)
+        return O.h2o_update_kv(k, q, v, w, cap, topk_mode=mode, return_indices=True, merge=mg)
     if pol == "streamingllm":
-        return O.streamingllm_update_kv(k, q, v, w, cap, return_indices=True)
+        return O.streamingllm_update_kv(k, q, v, w, cap, return_indices=True, merge=mg)
     raise ValueError(pol)
 
 
@@ -66,13 +67,14 @@ def test_restatement_bit_identical_to_reference(c):
         return
     assert np.array_equal(bits(kc), z["kc"])
     assert np.array_equal(bits(vc), z["vc"])
-    assert np.array_equal(idx.numpy().astype(np.int32), z["idx"])
+    if "idx" in z.files:                    # merge fixtures (merge_kv, :119-170) carry the merged K/V only
+        assert np.array_equal(idx.numpy().astype(np.int32), z["idx"])
 
 
 @pytest.mark.parametrize("c", DENSE, ids=[c["name"] for c in DENSE])
 def test_canonical_tie_rule_equivalent_to_reference(c):
     z, q, k, v = _load(c)
-    if bool(z["passthrough"]):
+    if bool(z["passthrough"]) or c.get("merge"):
         return
     kc, vc, idx = _run(c, q, k, v, "canonical")
     ref_idx = torch.from_numpy(z["idx"].astype(np.int64))
@@ -136,7 +138,18 @@ def test_tie_free_fixtures_canonical_is_bit_identical_to_reference():
         z, q, k, v = _load(c)
         kc, vc, idx = _run(c, q, k, v, "canonical")
         assert np.array_equal(bits(kc), z["kc"]) and np.array_equal(bits(vc), z["vc"])
-        assert np.array_equal(idx.numpy().astype(np.int32), z["idx"])
+        if "idx" in z.files:
+            assert np.array_equal(idx.numpy().astype(np.int32), z["idx"])
+
+
+@pytest.mark.parametrize("c", [c for c in CASES if c.get("merge")], ids=[c["name"] for c in CASES if c.get("merge")])
+def test_merge_explicit_spec_equals_reference(c):
+    """oracle.merge_kv_explicit (the arithmetic the HIP merge kernels implement, written out element by element) against
+    the REAL reference's merged K/V, starting from the reference's own selection."""
+    z, q, k, v = _load(c)
+    _, _, idx = _run(c, q, k, v, "reference")
+    ke, ve = O.merge_kv_explicit(k, v, idx, c["w"])
+    assert np.array_equal(bits(ke), z["kc"]) and np.array_equal(bits(ve), z["vc"])
 
 
 def test_pyramid_budget_table():
