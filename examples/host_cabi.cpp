@@ -3,8 +3,9 @@
 // and checks on the host what can be checked without a second implementation: indices valid / distinct, scores of
 // the selected tokens descending with index-ascending ties (pkv_score_window re-run), K_c/V_c = exact gather of the
 // selected rows + the window tail.  Exit code 0 = all good.  Build: hipcc -I include examples/host_cabi.cpp
-//   -L pyramidkv_amd -lpkv -Wl,-rpath,'$ORIGIN/../pyramidkv_amd'
+//   -L pyramidkv_amd -lpkv -lrccl -Wl,-rpath,'$ORIGIN/../pyramidkv_amd'
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -83,6 +84,24 @@ int main() {
     for (int r = 0; r < w && !bad; ++r)
       if (memcmp(&hko[((size_t)bh * cap + k + r) * D], &hk[((size_t)bh * S + L + r) * D], D * 2) ||
           memcmp(&hvo[((size_t)bh * cap + k + r) * D], &hv[((size_t)bh * S + L + r) * D], D * 2)) { printf("row %d: window tail mismatch\n", bh); bad = 1; }
+  }
+  // the one exchange step of the head-sharded path over a real RCCL communicator (this box has one GPU: nranks = 1);
+  // a tensor-parallel host calls exactly this after its local pkv_compress (include/pkv.h: pkv_allgather_indices)
+  {
+    ncclUniqueId uid;
+    ncclComm_t comm;
+    if (ncclGetUniqueId(&uid) != ncclSuccess || ncclCommInitRank(&comm, 1, uid, 0) != ncclSuccess) { printf("RCCL init failed\n"); bad = 1; }
+    else {
+      int32_t* all;
+      HIP_OK(hipMalloc((void**)&all, (size_t)B * H * k * 4));
+      HIP_OK(hipMemsetAsync(all, 0xff, (size_t)B * H * k * 4, stream));
+      PKV_OK_(pkv_allgather_indices(comm, idx, all, B, H, k, nullptr, 0, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      std::vector<int32_t> hall((size_t)B * H * k);
+      HIP_OK(hipMemcpy(hall.data(), all, hall.size() * 4, hipMemcpyDeviceToHost));
+      if (memcmp(hall.data(), hidx.data(), hall.size() * 4)) { printf("pkv_allgather_indices: gathered indices differ\n"); bad = 1; }
+      ncclCommDestroy(comm);
+    }
   }
   // error convention: a bad descriptor is reported, nothing aborts
   pkv_desc e = d; e.D = 64;

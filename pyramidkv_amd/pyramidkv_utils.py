@@ -288,7 +288,7 @@ class _HostMirror:
         return a[:H].tolist()
 
 
-_ADA_TOPM_MAX = 8192      # longest per-head list taken from the top-k kernel; beyond it the rows are sorted completely
+_ADA_TOPM_MAX = 4096      # longest per-head list taken from the top-k kernel; beyond it the rows are sorted completely
 
 
 class _FlatPolicy:

@@ -231,7 +231,7 @@ def test_merge_compact_vs_oracle_given_indices(P, dt, kind):
     if kind == "lattice":
         assert torch.equal(km.cpu(), kr) and torch.equal(vm.cpu(), vr)
     else:
-        assert fk <= 0.02 and fv <= 0.02, (fk, fv)
+        assert fk == 0.0 and fv == 0.0, (fk, fv)          # measured: bit-identical on these seeds as well
 
 
 def test_merge_count_rounding_above_256(P):
