@@ -58,7 +58,32 @@ def stats_table(pattern, title, top=8):
     lines.append("")
 
 
-stats_table("prof", "rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline", 10)
+stats_table("prof_headline", "rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras (headline workload only)", 6)
+stats_table("prof", "rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline (all legs of the bench line mixed: B = 1 and B = 8, budgets 128 and 2048, un-expanded K)", 10)
+# the gather kernel of the full run split by launch grid: gather_kernel<8> with 16 row blocks x 32 heads = 512 workgroups is budget 2048 at
+# B = 1, 4096 workgroups is B = 8
+tr = sorted(glob.glob(os.path.join(G, "prof", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+if tr:
+    by = defaultdict(list)
+    for r in csv.DictReader(open(tr[-1])):
+        n = r["Kernel_Name"]
+        if "pkv::gather_kernel" in n:
+            by[(n.split("pkv::")[1].split("(")[0], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    rows = [{"kernel": k[0], "workgroups": k[1], "launches": len(v), "avg_us": round(sum(v) / len(v), 2), "min_us": round(min(v), 2)} for k, v in sorted(by.items())]
+    json.dump(rows, open(os.path.join(P, "rocprofv3_gather_by_grid.json"), "w"), indent=1)
+    lines += ["### gather_kernel of that run by launch grid (`rocprofv3_gather_by_grid.json`; 512 workgroups of gather_kernel<8> = budget 2048 at B = 1, 4096 = B = 8)\n",
+              "| kernel | workgroups | launches | avg us | min us |", "|---|---|---|---|---|"]
+    for r in rows:
+        lines.append("| %s | %d | %d | %.2f | %.2f |" % (r["kernel"], r["workgroups"], r["launches"], r["avg_us"], r["min_us"]))
+    lines.append("")
+# gather shape A/B of session 1 (rows per lane x XCD-aligned block map)
+shape = {}
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "s1", "sweep_rpt*_xcd*.json"))):
+    j = first_json_line(f)
+    if j:
+        shape[os.path.basename(f)[6:-5]] = {k: {"gather_us": v["gather"]["us"], "frac_of_8TBps": v["gather"]["frac_of_8TBps"]} for k, v in j.items()}
+if shape:
+    json.dump(shape, open(os.path.join(P, "gather_shape.json"), "w"), indent=1)
 pm = {}
 pj = os.path.join(G, "pmc_traffic.json")
 if os.path.exists(pj):
@@ -138,6 +163,9 @@ if tt:
     for k, v in tt.items():
         lines.append("| %s | %s | %s | %s |" % (k, v["C"], v["total"], v["stamps_rel"]))
     lines.append("")
+sm = os.path.join(G, "smoke.log")
+if os.path.exists(sm):
+    shutil.copy(sm, os.path.join(P, "smoke.log"))
 py = os.path.join(G, "pytest.txt")
 if os.path.exists(py):
     lines += ["## GPU test suite\n", "```", "".join(open(py).readlines()[-12:]).strip(), "```", ""]

@@ -22,9 +22,14 @@ timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extras --allgather layer > $O/bench_rccl_n1_perlayer.json 2> $O/bench_rccl_n1_perlayer.log
 PKV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_n2_gloo.json 2> $O/bench_n2_gloo.log
 cd /tmp
-# rocprofv3 of the bench command (kernel trace + stats), then PMC traffic in separate passes
+# rocprofv3 of the bench command (kernel trace + stats): headline workload alone, then the full line (grid, baselines), then
+# PMC traffic in separate passes
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_headline -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/rocprof_headline.log 2>&1
+echo "rocprof headline exit $?" >> $O/rocprof_headline.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof.log 2>&1
 echo "rocprof exit $?" >> $O/rocprof.log
+python $R/__graft_entry__.py smoke > $O/smoke.log 2>&1
+echo "smoke exit $?" >> $O/smoke.log
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_write.log 2>&1
 python $R/tools/pmc_summary.py $O $O/pmc_traffic.json > $O/pmc_summary.log 2>&1
