@@ -284,3 +284,52 @@ def test_merge_golden_fixtures_and_clusters(P):
         fk, _ = _merge_close(km.cpu(), kr)
         fv, _ = _merge_close(vm.cpu(), vr)
         assert fk <= (0.0 if c["kind"] == "lattice" else 0.02) and fv <= (0.0 if c["kind"] == "lattice" else 0.02), (c["name"], fk, fv)
+
+
+def test_merge_randomised_configs(P):
+    """16 seeded random merge configurations - batch, heads, un-expanded GQA K/V (kv_group), strided [B,S,H,D] storage, S not a
+    multiple of anything, window, k, dtype, lattice inputs (every norm / dot product exact in fp32 in any order): the merged
+    K/V are bit-identical to oracle.merge_kv run on the repeat_kv-expanded tensors."""
+    rng = np.random.default_rng(17)
+    for case in range(16):
+        B = int(rng.integers(1, 3))
+        g = int(rng.choice([1, 1, 2, 4]))
+        Hk = int(rng.integers(1, 4))
+        H = Hk * g
+        w = int(rng.choice([1, 4, 8, 16, 32]))
+        S = int(rng.integers(w + 60, 3000))
+        k = int(rng.integers(1, min(S - w, 300) + 1))
+        dt = "bf16" if case % 2 else "fp16"
+        _, K, V = make_qkv(B, H, S, 128, dt, "lattice", 7300 + case)
+        K[:, :, ::3] = (K[:, :, ::3].float() * 0.5).to(K.dtype)                    # different norms, still exact
+        k_un, v_un = K[:, ::g].contiguous(), V[:, ::g].contiguous()
+        k_exp = k_un[:, :, None].expand(B, Hk, g, S, 128).reshape(B, H, S, 128).contiguous()
+        v_exp = v_un[:, :, None].expand(B, Hk, g, S, 128).reshape(B, H, S, 128).contiguous()
+        gen = torch.Generator().manual_seed(case)
+        idx = torch.stack([torch.stack([torch.randperm(S - w, generator=gen)[:k] for _ in range(H)]) for _ in range(B)])
+        kr, vr = O.merge_kv(k_exp, v_exp, idx, w, "pivot")
+        if case % 3 == 0:      # [B, S, Hk, D] storage seen through a transposed view
+            kd = k_un.to(DEV).transpose(1, 2).contiguous().transpose(1, 2)
+            vd = v_un.to(DEV).transpose(1, 2).contiguous().transpose(1, 2)
+        else:
+            kd, vd = k_un.to(DEV), v_un.to(DEV)
+        km, vm = P.ops.merge_compact(kd, vd, idx.to(DEV).int(), w, kv_group=g)
+        assert torch.equal(km.cpu(), kr) and torch.equal(vm.cpu(), vr), (case, B, H, g, S, w, k, dt)
+
+
+def test_merge_cluster_unexpanded_gqa_equals_expanded(P):
+    """SnapKVCluster(merge='pivot') handed K/V before repeat_kv (4 query heads per KV head) == the same cluster on the
+    expanded tensors == the oracle on the HIP path's own indices."""
+    B, Hq, Hkv, S, w, cap = 1, 8, 2, 2048, 8, 64
+    g = Hq // Hkv
+    q, k8, v8 = make_qkv(B, Hq, S, 128, "bf16", "gauss", 7400)
+    k_un, v_un = k8[:, ::g].contiguous(), v8[:, ::g].contiguous()
+    k_exp = k_un[:, :, None].expand(B, Hkv, g, S, 128).reshape(B, Hq, S, 128).contiguous()
+    v_exp = v_un[:, :, None].expand(B, Hkv, g, S, 128).reshape(B, Hq, S, 128).contiguous()
+    cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool", merge="pivot")
+    ka, va = cl.update_kv(k_un.to(DEV), q.to(DEV), v_un.to(DEV), None, g)
+    kb, vb = cl.update_kv(k_exp.to(DEV), q.to(DEV), v_exp.to(DEV), None, g)
+    assert torch.equal(ka, kb) and torch.equal(va, vb)
+    idx = P.ops.select(q.to(DEV), k_un.to(DEV), w, cap - w, "maxpool", 7, kv_group=g).cpu().long()
+    kr, vr = O.merge_kv(k_exp, v_exp, idx, w, "pivot")
+    assert torch.equal(ka.cpu(), kr) and torch.equal(va.cpu(), vr)
