@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void merge_targets_kernel(MergeParams p) {
 // ---- 4. pivot: for every dropped row the kept row with the largest cosine similarity (first maximum) ----
 // One wave = 16 dropped rows (MFMA A operand, unit-normalised in registers); the kept rows stream through LDS in tiles
 // of MP_TN targets as B operands; a workgroup walks MP_ITER row groups against the staged tile before the next tile.
-constexpr int MP_TN = 128;                // kept rows per LDS tile (32 KB)
+constexpr int MP_TN = 144;                // kept rows per LDS tile (39 KB): budget 128 + window 8 in ONE tile
 constexpr int MP_ROWS = 64;               // dropped rows per workgroup pass (4 waves x 16)
 constexpr int MP_ITER = 4;                // passes per workgroup: 256 dropped rows per workgroup
 constexpr int MP_TROW = 136;              // LDS row stride in elements (272 B: the 16 rows of a B fragment hit different banks)
@@ -106,32 +106,39 @@ __global__ __launch_bounds__(256) void merge_pivot_kernel(MergeParams p) {
   const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const uint16_t* tn = reinterpret_cast<const uint16_t*>(p.tn) + (int64_t)bh * p.ntp * 128;
 
-  // A operands of this wave's MP_ITER row groups: row li of group it = dropped row row_wg + it*64 + wave*16 + li
+  // A operands of this wave's MP_ITER row groups: row li of group it = dropped row row_wg + it*64 + wave*16 + li.
+  // All 16 row loads of a lane are issued before any of them is used (one round trip instead of four).
   u32x4 af[MP_ITER][4];
 #pragma unroll
   for (int it = 0; it < MP_ITER; ++it) {
     int r = row_wg + it * MP_ROWS + wave * 16 + li;
     r = r < n ? r : n - 1;                                               // clamp: rows past n are never written
     const uint16_t* row = kbase + (int64_t)p.drop[r] * p.ks_s + lg * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) af[it][kk] = *reinterpret_cast<const u32x4*>(row + kk * 32);
+  }
+#pragma unroll
+  for (int it = 0; it < MP_ITER; ++it) {
     float xs[32];
     float n2 = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       U4 u;
-      u.v = *reinterpret_cast<const uint4*>(row + kk * 32);
+      u.v = make_uint4(af[it][kk].x, af[it][kk].y, af[it][kk].z, af[it][kk].w);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { xs[kk * 8 + e] = Elem<T>::to_f32(u.h[e]); n2 += xs[kk * 8 + e] * xs[kk * 8 + e]; }
     }
     n2 += __shfl_xor(n2, 16, 64);                                         // the row's 128 elements sit in 4 lanes (lg)
     n2 += __shfl_xor(n2, 32, 64);
     const float nr = Elem<T>::to_f32(Elem<T>::from_f32(sqrtf(n2)));
+    const float rn = 1.0f / nr;                                           // one division per row; div_const = correctly rounded x / nr
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       u32x4 a;
-      a.x = round_pack2<T>(xs[kk * 8 + 0] / nr, xs[kk * 8 + 1] / nr);
-      a.y = round_pack2<T>(xs[kk * 8 + 2] / nr, xs[kk * 8 + 3] / nr);
-      a.z = round_pack2<T>(xs[kk * 8 + 4] / nr, xs[kk * 8 + 5] / nr);
-      a.w = round_pack2<T>(xs[kk * 8 + 6] / nr, xs[kk * 8 + 7] / nr);
+      a.x = round_pack2<T>(div_const(xs[kk * 8 + 0], nr, rn), div_const(xs[kk * 8 + 1], nr, rn));
+      a.y = round_pack2<T>(div_const(xs[kk * 8 + 2], nr, rn), div_const(xs[kk * 8 + 3], nr, rn));
+      a.z = round_pack2<T>(div_const(xs[kk * 8 + 4], nr, rn), div_const(xs[kk * 8 + 5], nr, rn));
+      a.w = round_pack2<T>(div_const(xs[kk * 8 + 6], nr, rn), div_const(xs[kk * 8 + 7], nr, rn));
       af[it][kk] = a;
     }
   }
@@ -192,12 +199,18 @@ __global__ __launch_bounds__(256) void merge_pivot_kernel(MergeParams p) {
 
 // ---- 5. scatter-mean: kept row j collects, in ascending order, the dropped rows that chose it ----
 // Workgroup = one kept row of one (b,h): threads 0..127 = the 128 elements of the KEY row, 128..255 of the VALUE row.
-constexpr int MS_LIST = 2048;
+// The ordered source list is built without barriers: wave w scans the w-th quarter of a chunk of MS_CHUNK pivots (8 loads in
+// flight per lane, ballot + mbcnt compaction into its own LDS segment); the four segments in wave order are the ascending
+// list.  The walk keeps two batches of 16 row loads in flight (the next batch is issued before the current one is consumed):
+// the fp32 accumulation order is the list order, whatever the latency of a row.
+constexpr int MS_CHUNK = 8192;            // pivots per pass (2048 per wave)
+constexpr int MS_SEG = MS_CHUNK / 4;      // LDS list segment per wave
+constexpr int MS_B = 32;                  // rows per batch of the walk (all in flight together)
 
 template <typename T>
 __global__ __launch_bounds__(256) void merge_scatter_kernel(MergeParams p) {
-  __shared__ int32_t list[MS_LIST];
-  __shared__ uint32_t wtot[4];
+  __shared__ int32_t list[MS_CHUNK];
+  __shared__ uint32_t wcount[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = tid & 127, is_v = tid >> 7;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
@@ -212,41 +225,61 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(MergeParams p) {
   const float t = Elem<T>::to_f32(base[(int64_t)tpos * sstride + d]);     // the kept row BEFORE merging (gather at :157/:160)
   float acc = t;                                                          // include_self
   int cnt = 1;
-  for (int c0 = 0; c0 < n; c0 += MS_LIST) {
-    // ordered list of the dropped rows in [c0, c0 + MS_LIST) whose pivot is j
+  for (int c0 = 0; c0 < n; c0 += MS_CHUNK) {
+    __syncthreads();                                                      // the previous chunk's list has been walked
+    // wave-private scan of [c0 + wave*MS_SEG, +MS_SEG): 8 pivot loads in flight per lane, no barrier inside
     uint32_t run = 0;
-    __syncthreads();
-    for (int s0 = c0; s0 < min(n, c0 + MS_LIST); s0 += 256) {
-      const int i = s0 + tid;
-      const bool hit = i < n && i < c0 + MS_LIST && piv[i] == j;
-      const uint64_t bal = __ballot(hit);
-      const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-      if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
-      __syncthreads();
-      uint32_t lower = 0, all = 0;
+    const int w0 = c0 + wave * MS_SEG;
+    for (int s0 = w0; s0 < min(n, w0 + MS_SEG); s0 += 8 * 64) {
+      int pv[8], dr[8];      // pivots AND drop positions up front: a drop[] load behind a hit would stall every hit for a round trip
 #pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) { const uint32_t c = wtot[w2]; all += c; lower += w2 < wave ? c : 0u; }
-      if (hit) list[run + lower + before] = p.drop[i];
-      run += all;
-      __syncthreads();
-    }
-    // ascending walk, 8 row loads in flight (clamped reads, masked use); fp32 accumulation in list order
-    for (uint32_t l0 = 0; l0 < run; l0 += 8) {
-      uint16_t x[8];
+      for (int u = 0; u < 8; ++u) { const int i = s0 + u * 64 + lane; pv[u] = piv[i < n ? i : n - 1]; dr[u] = p.drop[i < n ? i : n - 1]; }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const uint32_t l = l0 + u < run ? l0 + u : run - 1;
-        x[u] = base[(int64_t)list[l] * sstride + d];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (l0 + u < run) {
-          const float half = Elem<T>::to_f32(Elem<T>::from_f32(Elem<T>::to_f32(x[u]) + t)) * 0.5f;   // (x + t) -> dtype, / 2 (:158)
-          acc = __fadd_rn(acc, Elem<T>::to_f32(Elem<T>::from_f32(half)));
+        const int i = s0 + u * 64 + lane;
+        const bool hit = i < n && i < w0 + MS_SEG && pv[u] == j;
+        const uint64_t bal = __ballot(hit);
+        if (bal != 0ull) {
+          const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          if (hit) list[wave * MS_SEG + run + before] = dr[u];
+          run += (uint32_t)__popcll(bal);
         }
       }
     }
-    cnt += (int)run;
+    if (lane == 0) wcount[wave] = run;
+    __syncthreads();
+    // ascending walk over the four segments as ONE list (entry l lives in segment sg at l - first[sg]); batches of MS_B rows,
+    // the next batch in flight while the current one is consumed: one exposed row latency per pass, not one per segment
+    const uint32_t f1 = wcount[0], f2 = f1 + wcount[1], f3 = f2 + wcount[2], m = f3 + wcount[3];
+    auto entry = [&](uint32_t l) -> int32_t {
+      l = l < m ? l : (m ? m - 1 : 0u);
+      const uint32_t sg = (l >= f1) + (l >= f2) + (l >= f3);
+      const uint32_t first = sg == 0 ? 0u : (sg == 1 ? f1 : (sg == 2 ? f2 : f3));
+      return list[sg * MS_SEG + (l - first)];
+    };
+    // Every lane would otherwise repeat the (wave-uniform) list look-up and 64-bit address arithmetic for every row: ~15
+    // vector instructions per row and lane made this walk VALU-bound.  Instead each lane looks up ONE entry of a block of 64
+    // rows; the row numbers then reach the scalar unit through v_readlane and the loads use a scalar base.
+    for (uint32_t l64 = 0; l64 < m; l64 += 64) {
+      const int myrow = entry(l64 + (uint32_t)lane);
+      const uint32_t left = m - l64 < 64u ? m - l64 : 64u;
+      for (uint32_t b0 = 0; b0 < left; b0 += MS_B) {
+        uint16_t x[MS_B];
+#pragma unroll
+        for (int u = 0; u < MS_B; ++u) {
+          const int r = __builtin_amdgcn_readlane(myrow, (int)(b0 + u < 64u ? b0 + u : 63u));   // rows past `left` repeat the last entry (masked below)
+          x[u] = base[(int64_t)r * sstride + d];
+        }
+#pragma unroll
+        for (int u = 0; u < MS_B; ++u) {
+          if (b0 + u < left) {
+            const float half = Elem<T>::to_f32(Elem<T>::from_f32(Elem<T>::to_f32(x[u]) + t)) * 0.5f;   // (x + t) -> dtype, / 2 (:158)
+            acc = __fadd_rn(acc, Elem<T>::to_f32(Elem<T>::from_f32(half)));
+          }
+        }
+      }
+    }
+    cnt += (int)m;
   }
   const float sum_q = Elem<T>::to_f32(Elem<T>::from_f32(acc));            // the scattered SUM in the model dtype
   const float cnt_q = Elem<T>::to_f32(Elem<T>::from_f32((float)cnt));     // the count in the model dtype (rounds above 256 / 2048)
