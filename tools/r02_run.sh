@@ -6,6 +6,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/run
 mkdir -p $O
 cd $R
-timeout 1500 python -m pytest -m gpu -q --timeout 900 $@ > $O/pytest.txt 2>&1
+timeout 1500 python -m pytest -m gpu -q --timeout 900 "$@" > $O/pytest.txt 2>&1
 echo "pytest exit $?" >> $O/pytest.txt
 tail -60 $O/pytest.txt
