@@ -158,9 +158,12 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     }
     const int sph = (d->S + 127) / 128;                                     // stages per head group
     const int64_t total = (int64_t)d->B * (d->H / d->kv_group) * sph;
-    // workgroups: 8 per CU for C = 8 (measured best of 3..16, all within 3 %); 4 per CU when a stage carries more columns
-    // (un-expanded GQA K: 2048 single-stage workgroups cost 2.5 us more than 256..1024 with 2..8 stages each)
-    const int target = logits_v2_wgs() > 0 ? logits_v2_wgs() : (C > 8 ? 4 : 8) * cus;
+    // stages per workgroup.  C <= 8 columns (expanded K/V, window 8): ONE stage per workgroup - measured in round 2 over
+    // {1, 2, 3, 4, 8 stages}: 1 is the fastest at B = 1 (45.1-46.0 us against 45.7-48.6 us for 4 stages in the same
+    // sessions; 2 and 3 stages are the slowest) and at B = 8 (350 vs 353 us): the in-workgroup pipeline only pays when few
+    // workgroups share a CU.  More columns per stage (un-expanded GQA K, C = 32): 4 workgroups per CU with 2..8 stages each
+    // (one stage per workgroup costs +4 us there).
+    const int64_t target = logits_v2_wgs() > 0 ? logits_v2_wgs() : (C > 8 ? (int64_t)4 * cus : total);
     int nst = (int)((total + target - 1) / target);
     nst = std::max(1, std::min(nst, std::min(sph, 64)));
     lp.nst = nst;
