@@ -104,8 +104,8 @@ int main() {
     }
   }
   // error convention: a bad descriptor is reported, nothing aborts
-  pkv_desc e = d; e.D = 64;
-  if (pkv_compress(&e, q, kk, v, ko, vo, idx, ws, wsb, stream) != PKV_ERR_SHAPE) { printf("D=64 not rejected\n"); bad = 1; }
+  pkv_desc e = d; e.D = 100;
+  if (pkv_compress(&e, q, kk, v, ko, vo, idx, ws, wsb, stream) != PKV_ERR_SHAPE) { printf("D=100 not rejected\n"); bad = 1; }
   printf(bad ? "host_cabi: FAILED\n" : "host_cabi: ok (pkv_version %d, %d heads x top-%d of %d, workspace %zu bytes)\n", pkv_version(), B * H, k, L, wsb);
   return bad;
 }

@@ -33,7 +33,7 @@ typedef void* pkv_stream_t; /* hipStream_t */
 enum pkv_status {
   PKV_OK = 0,
   PKV_ERR_DTYPE = -1,       /* dtype not bf16/fp16 */
-  PKV_ERR_SHAPE = -2,       /* D != 128, window/topk out of range, k > L ... */
+  PKV_ERR_SHAPE = -2,       /* D not in {64,128,256}, window/topk out of range, k > L ... */
   PKV_ERR_ALIGN = -3,       /* pointer or stride breaks 16-byte row alignment */
   PKV_ERR_WORKSPACE = -4,   /* workspace too small */
   PKV_ERR_UNSUPPORTED = -5, /* valid request outside the limits of this build */
@@ -51,7 +51,8 @@ enum pkv_scale { PKV_SCALE_DIV = 0, PKV_SCALE_RCP = 1 };
 
 typedef struct pkv_desc {
   int32_t dtype;        /* pkv_dtype of q,k,v and of every score buffer */
-  int32_t B, H, S, D;   /* H = number of query heads; D must be 128 */
+  int32_t B, H, S, D;   /* H = number of query heads; D = 128 (all entry points) or 64 / 256 (not pkv_score_h2o,
+                           pkv_compress_h2o, pkv_merge_compact: PKV_ERR_UNSUPPORTED) */
   int32_t kv_group;     /* 1: k,v have H heads (post-repeat_kv, the reference contract).
                            g>1: k,v have H/g heads (un-expanded GQA); head h reads kv head h/g */
   int64_t q_stride[3];  /* element strides of q for b,h,s */

@@ -90,7 +90,7 @@ struct ProfScope {
 int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true) {
   if (!d) return PKV_ERR_NULL;
   if (d->dtype != PKV_BF16 && d->dtype != PKV_F16) return PKV_ERR_DTYPE;
-  if (d->D != 128) return PKV_ERR_SHAPE;
+  if (d->D != 64 && d->D != 128 && d->D != 256) return PKV_ERR_SHAPE;      // H2O and the merge: 128 only (checked there)
   if (d->B < 1 || d->H < 1 || d->S < 2) return PKV_ERR_SHAPE;
   if (d->kv_group < 1 || d->H % d->kv_group) return PKV_ERR_SHAPE;
   if (d->window < 1 || d->window >= d->S) return PKV_ERR_SHAPE;
@@ -141,8 +141,9 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   lp.q = q; lp.k = k;
   lp.logits = ws + L.off_logits;
   lp.partial = reinterpret_cast<float2*>(ws + L.off_partial);
-  lp.B = d->B; lp.H = d->H; lp.S = d->S; lp.w = d->window; lp.G = d->kv_group;
-  lp.Sp = L.Sp; lp.nT = L.nT; lp.nst = 0; lp.tile = logits_tile(); lp.nt = logits_nt(); lp.ablate = logits_ablate(); lp.wgtrace = g_wg_trace;
+  lp.B = d->B; lp.H = d->H; lp.S = d->S; lp.w = d->window; lp.G = d->kv_group; lp.D = d->D;
+  lp.Sp = L.Sp; lp.nT = L.nT; lp.nst = 0; lp.tile = d->D == 256 ? 128 : logits_tile();   // 512-byte rows: 32 keys per wave (register budget)
+  if (d->D == 256) lp.nT = (d->S + 127) / 128; lp.nt = logits_nt(); lp.ablate = logits_ablate(); lp.wgtrace = g_wg_trace;
   lp.qs_b = d->q_stride[0]; lp.qs_h = d->q_stride[1]; lp.qs_s = d->q_stride[2];
   lp.ks_b = d->k_stride[0]; lp.ks_h = d->k_stride[1]; lp.ks_s = d->k_stride[2];
   lp.scale_mode = d->scale_mode;
@@ -150,7 +151,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   lp.rcp_sqrt_d = 1.0f / lp.sqrt_d;        // ATen GPU path: a * (1.0f / b)
   const int C = d->kv_group * d->window;
   int nT_used = L.nT;
-  if (logits_v2() && C <= 32 && !g_wg_trace) {
+  if (logits_v2() && C <= 32 && d->D == 128 && !g_wg_trace) {
     static int cus = 0;
     if (!cus) {
       int dev = 0;
@@ -173,6 +174,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     hipError_t e = launch_logits2(d->dtype, lp, st);
     if (e != hipSuccess) return hip_fail(e);
   } else {
+    nT_used = lp.nT;
     ProfScope ps(PKV_K_LOGITS, st, true);
     hipError_t e = launch_logits(d->dtype, lp, st);
     if (e != hipSuccess) return hip_fail(e);
@@ -283,7 +285,7 @@ GatherParams make_gather(const pkv_desc* d, const void* k, const void* v, void* 
   g.idx = nullptr; g.idx_stride = 0; g.head_k = nullptr; g.cu_rows = nullptr; g.wgtrace = g_wg_trace;
   g.rpt = gather_rpt(); g.xcd_map = gather_xcd(); g.nblk = 0;
   g.out_rows = (int64_t)d->B * d->H * (d->topk + d->window);          // dense layout; pkv_gather_flat overrides it
-  g.B = d->B; g.H = d->H; g.S = d->S; g.w = d->window; g.nsel = d->topk; g.G = d->kv_group;
+  g.B = d->B; g.H = d->H; g.S = d->S; g.w = d->window; g.nsel = d->topk; g.G = d->kv_group; g.D = d->D;
   g.ks_b = d->k_stride[0]; g.ks_h = d->k_stride[1]; g.ks_s = d->k_stride[2];
   g.vs_b = d->v_stride[0]; g.vs_h = d->v_stride[1]; g.vs_s = d->v_stride[2];
   return g;
@@ -308,6 +310,7 @@ int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, c
   char* w = static_cast<char*>(ws);
   void* scores = w + L.off_scores;
   const bool cm = !h2o && env_int("PKV_TOPK_CMAX", 1) != 0;   // chunk maxima feed the top-k prefilter
+  if (h2o && d->D != 128) return PKV_ERR_UNSUPPORTED;
   rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
   int32_t* idx = idx_out ? idx_out : reinterpret_cast<int32_t*>(w + L.off_idx);
@@ -366,6 +369,7 @@ int pkv_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores_
   int rc = check_desc(d, false);
   if (rc) return rc;
   if (!q || !k || !scores_out || !ws) return PKV_ERR_NULL;
+  if (d->D != 128) return PKV_ERR_UNSUPPORTED;
   if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
   WsLayout L = ws_layout(d);
   if (ws_bytes < L.total) return PKV_ERR_WORKSPACE;
@@ -435,6 +439,7 @@ int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int
   if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
   WsLayout L = ws_layout(d);
   if (ws_bytes < (h2o ? L.total : L.off_rowstat)) return PKV_ERR_WORKSPACE;
+  if (h2o && d->D != 128) return PKV_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* w = static_cast<char*>(ws);
   void* scores = w + L.off_scores;
@@ -473,6 +478,7 @@ int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int
   if (!k || !v || !idx || !k_out || !v_out || !ws) return PKV_ERR_NULL;
   if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out) || misaligned(ws)) return PKV_ERR_ALIGN;
   if (idx_stride < d->topk) return PKV_ERR_SHAPE;
+  if (d->D != 128) return PKV_ERR_UNSUPPORTED;
   MergeWs m = merge_ws(d);
   if (ws_bytes < m.total) return PKV_ERR_WORKSPACE;
   char* w = static_cast<char*>(ws);

@@ -19,12 +19,15 @@ namespace pkv {
 // for speed only): the indices of head bh were written by top-k workgroup bh, i.e. on XCD bh % 8, and the gather
 // blocks of that head are placed on the same XCD, where the index lines are still in the L2 - the one dependent
 // round trip before any row can move is then an L2 hit instead of a trip to the fabric.
-template <int RPT>
+// CH = 16-B chunks per row = head_dim / 8 (8, 16, 32 for head sizes 64, 128, 256): 256 / CH row slots per pass.
+template <int RPT, int CH>
 __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
-  constexpr int ROWS = 16 * RPT;
+  constexpr int SLOTS = 256 / CH;
+  constexpr int ROWS = SLOTS * RPT;
+  constexpr int DH = CH * 8;           // head size in elements
   const int tid = threadIdx.x;
-  const int chunk = tid & 15;          // 16-B chunk of the 256-B row
-  const int slot = tid >> 4;           // 16 row slots
+  const int chunk = tid % CH;          // 16-B chunk of the row
+  const int slot = tid / CH;           // row slot
   const int BH = p.B * p.H;
   int bh, blk;
   if (p.xcd_map) {                     // BH % 8 == 0 (host-checked)
@@ -60,16 +63,16 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
     const int last = nsel > 0 ? nsel - 1 : 0;
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-      const int r = r_blk + j * 16 + slot;
+      const int r = r_blk + j * SLOTS + slot;
       gi[j] = __builtin_nontemporal_load(ib + (r < last ? r : last));
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) gi[j] = r_blk + j * 16 + slot;
+    for (int j = 0; j < RPT; ++j) gi[j] = r_blk + j * SLOTS + slot;
   }
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
-    const int r = r_blk + j * 16 + slot;
+    const int r = r_blk + j * SLOTS + slot;
     ok[j] = r < nrows && out_row0 + r < p.out_rows;          // out_rows: rows the output buffers hold (flat layout: a bound)
     // a selected index outside [0, L) (the reference's gather raises there) is clamped: never an out-of-bounds read
     const int g = min(max(gi[j], 0), L - 1);
@@ -87,9 +90,9 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     if (ok[j]) {
-      const int64_t orow = out_row0 + r_blk + j * 16 + slot;
-      __builtin_nontemporal_store(kd[j], reinterpret_cast<u32x4*>(ko + orow * 128));
-      __builtin_nontemporal_store(vd[j], reinterpret_cast<u32x4*>(vo + orow * 128));
+      const int64_t orow = out_row0 + r_blk + j * SLOTS + slot;
+      __builtin_nontemporal_store(kd[j], reinterpret_cast<u32x4*>(ko + orow * DH));
+      __builtin_nontemporal_store(vd[j], reinterpret_cast<u32x4*>(vo + orow * DH));
     }
   }
   if (PKV_WGTRACE(p) && tid == 0) {
@@ -104,15 +107,22 @@ hipError_t launch_gather(const GatherParams& p0, int max_rows, hipStream_t st) {
   // 67 MB at B = 1), small budgets are launch-latency-bound and finish earlier with many small workgroups (measured, profiles/)
   int rpt = p.rpt;
   if (rpt != 2 && rpt != 4 && rpt != 8 && rpt != 16) rpt = max_rows >= 1024 ? 8 : 2;
-  const int rows = 16 * rpt;
+  const int ch = p.D / 8;
+  if (ch != 16 && rpt == 16) rpt = 8;                       // the 16-row variant exists for 256-byte rows only
+  const int rows = (256 / ch) * rpt;
   const int BH = p.B * p.H;
   p.nblk = (max_rows + rows - 1) / rows;
   if (BH % 8 != 0) p.xcd_map = 0;
   dim3 grid((unsigned)(p.nblk * BH));
-  if (rpt == 2) PKV_KLAUNCH(gather_kernel<2>, grid, dim3(256), 0, st, p);
-  else if (rpt == 16) PKV_KLAUNCH(gather_kernel<16>, grid, dim3(256), 0, st, p);
-  else if (rpt == 8) PKV_KLAUNCH(gather_kernel<8>, grid, dim3(256), 0, st, p);
-  else PKV_KLAUNCH(gather_kernel<4>, grid, dim3(256), 0, st, p);
+#define PKV_G(R, C) PKV_KLAUNCH((gather_kernel<R, C>), grid, dim3(256), 0, st, p)
+  if (ch == 16) {
+    if (rpt == 2) PKV_G(2, 16); else if (rpt == 16) PKV_G(16, 16); else if (rpt == 8) PKV_G(8, 16); else PKV_G(4, 16);
+  } else if (ch == 8) {
+    if (rpt == 2) PKV_G(2, 8); else if (rpt == 8) PKV_G(8, 8); else PKV_G(4, 8);
+  } else {
+    if (rpt == 2) PKV_G(2, 32); else if (rpt == 8) PKV_G(8, 32); else PKV_G(4, 32);
+  }
+#undef PKV_G
   return hipGetLastError();
 }
 

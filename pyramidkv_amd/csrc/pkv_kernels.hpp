@@ -41,6 +41,7 @@ struct LogitsParams {
   void* logits;      // [B*H*w][Sp] model dtype
   float2* partial;   // [B*H*w][nT] (tile row max, tile sum exp)
   int B, H, S, w, G; // G = kv_group
+  int D;             // head size: 64, 128 or 256 (logits2_kernel: 128 only)
   int Sp, nT;
   int tile;          // keys per workgroup: 128 or 256 (nT = ceil(S / tile))
   int nt;            // nontemporal K loads
@@ -104,6 +105,7 @@ struct GatherParams {
   const int32_t* head_k;     // per-(b,h) selected count (flat layout) or null -> uniform k
   const int32_t* cu_rows;    // per-(b,h) first output row (flat layout) or null -> bh*(k+w)
   int B, H, S, w, nsel, G;   // nsel = uniform selected-row count k
+  int D;                     // head size: 64, 128 or 256 (a row is D*2 bytes = D/8 lanes x 16 B)
   int64_t ks_b, ks_h, ks_s;
   int64_t vs_b, vs_h, vs_s;
   int rpt;                   // rows per lane and tensor: 2, 4 or 8 (16*rpt rows per workgroup)

@@ -23,7 +23,9 @@ namespace pkv {
 // never drains while other workgroups are in their MFMA / LDS / store phases.  K is streamed once
 // and never re-read: nontemporal loads (NT) keep it out of the way of the logits in L2.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KPW, bool NT>
+// KS = head_dim / 32 MFMA k-steps (2, 4, 8 for head sizes 64, 128, 256).  This kernel is the general one: logits2_kernel
+// below is specialised to 256-byte rows (head size 128) and takes over whenever it applies.
+template <typename T, int KPW, bool NT, int KS>
 __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   constexpr int TILE = 4 * KPW;            // keys per workgroup
   constexpr int LROW = TILE + 8;           // LDS row stride in elements (16-B aligned rows, <=2-way write conflicts)
@@ -50,17 +52,17 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   const int li = lane & 15;   // key within 16-subtile (A rows) / column within 16-tile (B cols)
   const int lg = lane >> 4;   // 8-element d-chunk within a 32-wide k-step
 
-  // ---- issue all K loads of this wave: NSUB subtiles x 4 k-steps x 16 B per lane ----
+  // ---- issue all K loads of this wave: NSUB subtiles x KS k-steps x 16 B per lane ----
   const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const int s_wave = t_idx * TILE + wave * KPW;
-  u32x4 kf[NSUB][4];
+  u32x4 kf[NSUB][KS];
 #pragma unroll
   for (int t = 0; t < NSUB; ++t) {
     int s = s_wave + t * 16 + li;
     s = s < S ? s : S - 1;  // clamp: stay in bounds; out-of-range keys are masked out of the stats below
     const uint16_t* row = kbase + (int64_t)s * p.ks_s + lg * 8;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < KS; ++kk) {
       const u32x4* ptr = reinterpret_cast<const u32x4*>(row + kk * 32);
       kf[t][kk] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
     }
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 #pragma unroll
     for (int t = 0; t < NSUB; ++t)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) a ^= kf[t][kk];
+      for (int kk = 0; kk < KS; ++kk) a ^= kf[t][kk];
     if ((a.x ^ a.y ^ a.z ^ a.w) == 0x12345678u) p.partial[0] = make_float2(0.f, 0.f);
     return;
   }
@@ -83,23 +85,23 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
   for (int n = 0; n < ntile_c; ++n) {
     // B fragments: column c = n*16 + li -> Q[b, h0 + c/w, S - w + c%w, kk*32 + lg*8 ..]
     const int c = n * 16 + li;
-    u32x4 qf[4];
+    u32x4 qf[KS];
     if (c < C) {
       const int hh = h0 + c / w;
       const int rr = c - (c / w) * w;
       const uint16_t* qrow = qb + (int64_t)hh * p.qs_h + (int64_t)(L + rr) * p.qs_s + lg * 8;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const u32x4*>(qrow + kk * 32);
+      for (int kk = 0; kk < KS; ++kk) qf[kk] = *reinterpret_cast<const u32x4*>(qrow + kk * 32);
     } else {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) qf[kk] = u32x4{0, 0, 0, 0};
+      for (int kk = 0; kk < KS; ++kk) qf[kk] = u32x4{0, 0, 0, 0};
     }
     const int rr_c = c % w;  // window row of this lane's column
 #pragma unroll
     for (int t = 0; t < NSUB; ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(kf[t][kk], qf[kk], acc);
+      for (int kk = 0; kk < KS; ++kk) acc = Mfma<T>::run(kf[t][kk], qf[kk], acc);
       if (PKV_ABLATE(p) == 2) {   // measurement aid: loads + MFMA only
         if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e30f) p.partial[0] = make_float2(0.f, 0.f);
         continue;
@@ -562,22 +564,27 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
   dim3 grid(p.nT, p.B * (p.H / p.G));
   const int tile = p.tile;
   const size_t lds = (size_t)C * (tile + 8) * sizeof(uint16_t);
-#define PKV_LAUNCH(TT, KPW, NT)                                                                                         \
+#define PKV_LAUNCH(TT, KPW, NT, KS)                                                                                     \
   do {                                                                                                                 \
     if (lds > 64 * 1024) {  /* wide GQA groups x wide windows: opt in to more than 64 KB of dynamic LDS */           \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(logits_kernel<TT, KPW, NT>),                  \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(logits_kernel<TT, KPW, NT, KS>),              \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
       if (e_ != hipSuccess) return e_;                                                                                \
     }                                                                                                                  \
-    PKV_KLAUNCH((logits_kernel<TT, KPW, NT>), grid, dim3(256), lds, st, p);                                           \
+    PKV_KLAUNCH((logits_kernel<TT, KPW, NT, KS>), grid, dim3(256), lds, st, p);                                       \
+  } while (0)
+#define PKV_LAUNCH_D(TT, KPW, NT)                                                                                      \
+  do {                                                                                                                 \
+    if (p.D == 64) PKV_LAUNCH(TT, KPW, NT, 2); else if (p.D == 256) PKV_LAUNCH(TT, KPW, NT, 8); else PKV_LAUNCH(TT, KPW, NT, 4); \
   } while (0)
   if (dtype == 0) {
-    if (tile == 128) { if (p.nt) PKV_LAUNCH(BF16, 32, true); else PKV_LAUNCH(BF16, 32, false); }
-    else             { if (p.nt) PKV_LAUNCH(BF16, 64, true); else PKV_LAUNCH(BF16, 64, false); }
+    if (tile == 128) { if (p.nt) PKV_LAUNCH_D(BF16, 32, true); else PKV_LAUNCH_D(BF16, 32, false); }
+    else             { if (p.nt) PKV_LAUNCH_D(BF16, 64, true); else PKV_LAUNCH_D(BF16, 64, false); }
   } else {
-    if (tile == 128) { if (p.nt) PKV_LAUNCH(F16, 32, true); else PKV_LAUNCH(F16, 32, false); }
-    else             { if (p.nt) PKV_LAUNCH(F16, 64, true); else PKV_LAUNCH(F16, 64, false); }
+    if (tile == 128) { if (p.nt) PKV_LAUNCH_D(F16, 32, true); else PKV_LAUNCH_D(F16, 32, false); }
+    else             { if (p.nt) PKV_LAUNCH_D(F16, 64, true); else PKV_LAUNCH_D(F16, 64, false); }
   }
+#undef PKV_LAUNCH_D
 #undef PKV_LAUNCH
   return hipGetLastError();
 }

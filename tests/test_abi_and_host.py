@@ -38,7 +38,7 @@ def test_strerror_and_argument_validation_without_gpu(P):
     N = P._native
     assert N.lib.pkv_strerror(0) == b"ok"
     d = N.PkvDesc()
-    d.dtype, d.B, d.H, d.S, d.D, d.kv_group, d.window, d.topk = 0, 1, 2, 64, 64, 1, 8, 4   # D != 128
+    d.dtype, d.B, d.H, d.S, d.D, d.kv_group, d.window, d.topk = 0, 1, 2, 64, 96, 1, 8, 4   # head size not in {64, 128, 256}
     assert N.lib.pkv_gather_streaming(d, 16, 16, 16, 16, None) == -2
     d.D = 128
     d.dtype = 7

@@ -333,3 +333,61 @@ def test_merge_cluster_unexpanded_gqa_equals_expanded(P):
     idx = P.ops.select(q.to(DEV), k_un.to(DEV), w, cap - w, "maxpool", 7, kv_group=g).cpu().long()
     kr, vr = O.merge_kv(k_exp, v_exp, idx, w, "pivot")
     assert torch.equal(ka.cpu(), kr) and torch.equal(va.cpu(), vr)
+
+
+# ----------------------------------------------------------------------------------------- head sizes other than 128
+@pytest.mark.parametrize("D", [64, 256])
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_head_sizes_64_and_256_window_policies(P, D, dt):
+    """The window policies, the gather and the flat var-len path at head sizes 64 and 256 (the reference is shape-generic,
+    pyramidkv_utils.py:317; its supported model families use 128): scores within 1 ulp of the oracle, indices == canonical top-k
+    of the kernel's own scores, K/V == exact gather incl. un-expanded GQA and strided views; Ada-SnapKV budgets and flat K/V
+    from the kernel's own scores == the oracle's arithmetic on them.  H2O and the merge are 128-only and say so."""
+    B, Hk, g, S, w, k = 2, 2, 2, 3001, 8, 77
+    H = Hk * g
+    q, kf, vf = make_qkv(B, H, S, D, dt, "gauss", 9500 + D)
+    k_un, v_un = kf[:, ::g].contiguous(), vf[:, ::g].contiguous()
+    k_exp = k_un[:, :, None].expand(B, Hk, g, S, D).reshape(B, H, S, D).contiguous()
+    v_exp = v_un[:, :, None].expand(B, Hk, g, S, D).reshape(B, H, S, D).contiguous()
+    qd = q.to(DEV)
+    kd = k_un.to(DEV).transpose(1, 2).contiguous().transpose(1, 2)            # [B,S,Hk,D] storage
+    vd = v_un.to(DEV)
+    for pool, ks in (("maxpool", 7), ("avgpool", 5)):
+        sg = P.ops.score_window(qd, kd, w, pool, ks, kv_group=g)
+        so = O.pool_scores(O.window_scores(q, k_exp, w), pool, ks)
+        frac, mx = score_diff(sg.cpu(), so)
+        assert mx <= 1 and frac <= SCORE_FRAC, (D, dt, pool, frac, mx)
+        kc, vc, idx = P.ops.compress(qd, kd, vd, w, k, pool, ks, kv_group=g, return_indices=True)
+        want = O.topk_canonical(sg.cpu(), k)
+        assert torch.equal(idx.cpu().long(), want)
+        kr, vr = O.gather_compact(k_exp, v_exp, want, w)
+        assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+    # a large budget (8 rows per lane in the gather) and StreamingLLM
+    kc, vc, idx = P.ops.compress(qd, kd, vd, w, 1500, "maxpool", 7, kv_group=g, return_indices=True)
+    kr, vr = O.gather_compact(k_exp, v_exp, idx.cpu().long(), w)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+    kc, vc = P.StreamingLLMKVCluster(window_size=60, max_capacity_prompt=64).update_kv(k_exp.to(DEV), qd, v_exp.to(DEV), None, 1)
+    kr, vr = O.streamingllm_update_kv(k_exp, q, v_exp, 60, 64)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+    # Ada-SnapKV (batch 1)
+    q1, k1, v1 = q[:1], k_exp[:1].contiguous(), v_exp[:1].contiguous()
+    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=64, floor=0.2, normalize=True)
+    kfl, vfl = cl.update_kv(k1.to(DEV), q1.to(DEV), v1.to(DEV))
+    s1 = P.ops.score_window(q1.to(DEV), k1.to(DEV), w, "maxpool", 7, "mean").cpu()
+    sidx, caps = O.adakv_head_capacity(s1, 64 - w, 0.2, True)
+    assert cl.head_lens.cpu().tolist() == [int(c) + w for c in caps[0]]
+    kr, vr, _ = O._flat_gather(k1, v1, [sidx[0, h, :int(caps[0, h])] for h in range(H)], w)
+    assert torch.equal(kfl.cpu(), kr) and torch.equal(vfl.cpu(), vr)
+    # decode-time flat append at this head size
+    cache = P.DynamicCacheSplitHeadFlatten()
+    cache.update(kfl, vfl, 0)
+    nk = torch.randn(1, H, 1, D).to(kfl.dtype)
+    knew, _ = cache.update(nk.to(DEV), nk.to(DEV), 0, {"head_lens": cl.head_lens, "cu_klen": cl.cu_klen})
+    want = O.update_flatten_view(kfl.cpu(), nk[0, :, 0], cl.head_lens.cpu(), cl.cu_klen.cpu())
+    assert torch.equal(knew.cpu(), want)
+    with pytest.raises(ValueError):
+        P.ops.score_h2o(qd, kd, w, kv_group=g)
+    with pytest.raises(ValueError):
+        P.ops.merge_compact(k_exp.to(DEV), v_exp.to(DEV), idx[:, :, :10].contiguous(), w)
+    with pytest.raises(ValueError):
+        P.ops.score_window(torch.zeros(1, 1, 64, 96, dtype=torch.bfloat16, device=DEV), torch.zeros(1, 1, 64, 96, dtype=torch.bfloat16, device=DEV), 8)
