@@ -15,11 +15,26 @@
 // probabilities, so the rare rounding flips (1e-6 / 2^-9 per element) average out far below the model-dtype
 // resolution of the sum (measured against the oracle in tests/test_gpu_parity.py::test_h2o_*), while the
 // kernels are instruction-issue-bound and the accurate exp costs 8 vector instructions per S x S element.
-// Roofline: compute.  2*2*S^2*D*H flops per call on the matrix cores; what actually bounds it is the SIMD issue port,
-// shared by the MFMAs and the ~10 vector instructions per S x S element of the rounding chain / exp (a quarter-rate
-// transcendental) / accumulate: ~190 issue cycles per 16x16 output block against 64 cycles of matrix-pipe time.
-// Issuing the next subtile's MFMAs ahead of the current epilogue (software pipelining) changed nothing (12.45 ->
-// 12.26 ms at 192 VGPRs): the port, not the MFMA latency, is the limit.
+//
+// Roofline: compute.  2*2*S^2*D*H flops per call on the matrix cores.  What bounds the kernels is the SIMD's issue
+// port: matrix and vector instructions of a SIMD barely overlap on gfx950 (tools/probes/mfma_valu_probe.hip: beside
+// one v_mfma_f32_16x16x32 two vector instructions are free, beside one 32x32x16 six, for one or two waves per SIMD
+// alike; every further one adds its full issue time), so time ~ matrix-pipe time + vector issue time and the lever is
+// the vector instruction count per S x S element:
+//   * bf16 rounding as v_cvt_pk_bf16_f32 v, 0, x: the rounded value lands in the HIGH half over a zero low half, which
+//     IS its fp32 representation - 1 instruction per rounding instead of pack + shift/mask (1.5);
+//   * no packed-fp32 arithmetic (v_pk_mul/fma_f32 cost several issue slots beside MFMAs);
+//   * pass 2 sums the columns ON THE MATRIX PIPE: P rounded to the model dtype is exact as an MFMA operand, so
+//     ones[16 x 32] x P[32 queries x 16 keys] adds 32 query rows per instruction into an fp32 accumulator (all 16 rows
+//     of the result hold the same sums) instead of unpack + add per element;
+//   * rows past S carry c_row = -inf (probability exactly 0) and tile loads are raw buffer loads whose addresses are
+//     advanced on the scalar unit and which return 0 past the end: no tail code, no per-tile vector address arithmetic;
+//   * pass 1 runs its end-of-row / masked-corner handling in a separate instance of the loop body.
+// Pass 1: 6.75 vector instructions per element (2 roundings + scale 3, fma, exp2, add, max 0.75), pass 2: 5.5 (3, fma,
+// exp2, pack 0.5) + 1/8 MFMA.  Tried and measured no better: a rotated loop with the next
+// sub-tile's MFMAs hand-interleaved between the epilogue's instructions (sched_barrier-pinned, 16x16x32 and 32x32x16 with
+// an LDS fragment ring).
+#include <type_traits>
 #include "pkv_common.hpp"
 #include "pkv_kernels.hpp"
 
@@ -40,53 +55,35 @@ template <> struct Mfma2<F16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
+template <typename T> struct Ones2;                   // two 1.0 of the model dtype
+template <> struct Ones2<BF16> { static constexpr uint32_t v = 0x3f803f80u; };
+template <> struct Ones2<F16> { static constexpr uint32_t v = 0x3c003c00u; };
 
+// v_max3_f32 on raw registers: fmaxf() of a value that came through integer bit operations makes the compiler
+// canonicalise it first (one extra v_max per operand)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// One logit through the reference's two roundings.
 template <typename T>
 __device__ __forceinline__ float logit_chain(float acc, const H2OParams& p) {
   float x = Elem<T>::to_f32(Elem<T>::from_f32(acc));                       // matmul output dtype (:544)
   x = scale_logit<T>(x, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);             // / math.sqrt(head_dim)
   return Elem<T>::to_f32(Elem<T>::from_f32(x));
 }
-
-// Four logits of one MFMA accumulator through the reference's two roundings.  bf16: the values travel as packed
-// pairs - one v_cvt_pk_bf16_f32 per two roundings, one shift / mask per unpack, the scale as a packed fp32
-// multiply (these kernels are VALU-bound: 13 -> ~10 vector-instruction equivalents per S x S element).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <>
+__device__ __forceinline__ float logit_chain<BF16>(float acc, const H2OParams& p) {
+  float x = __uint_as_float(round_pack2<BF16>(0.f, acc));                  // matmul output dtype (:544); low half = +0
+  x = x * p.rcp_sqrt_d;                                                    // / math.sqrt(head_dim): exact for bf16, see scale_logit
+  return __uint_as_float(round_pack2<BF16>(0.f, x));
+}
 template <typename T>
 __device__ __forceinline__ void logits4(const f32x4& acc, const H2OParams& p, float (&x)[4]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) x[r] = logit_chain<T>(acc[r], p);
-}
-template <>
-__device__ __forceinline__ void logits4<BF16>(const f32x4& acc, const H2OParams& p, float (&x)[4]) {
-  uint32_t p01 = round_pack2<BF16>(acc[0], acc[1]);                        // matmul output dtype (:544)
-  uint32_t p23 = round_pack2<BF16>(acc[2], acc[3]);
-  f32x2 a = {__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u)};
-  f32x2 b = {__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)};
-  const f32x2 rc = {p.rcp_sqrt_d, p.rcp_sqrt_d};                           // / math.sqrt(head_dim): exact for bf16, see scale_logit
-  a = a * rc;
-  b = b * rc;
-  p01 = round_pack2<BF16>(a.x, a.y);
-  p23 = round_pack2<BF16>(b.x, b.y);
-  x[0] = __uint_as_float(p01 << 16); x[1] = __uint_as_float(p01 & 0xffff0000u);
-  x[2] = __uint_as_float(p23 << 16); x[3] = __uint_as_float(p23 & 0xffff0000u);
-}
-// round four fp32 probabilities to the model dtype and return their fp32 sum ((p0 + p1) + (p2 + p3))
-template <typename T>
-__device__ __forceinline__ float round_sum4(const float (&e)[4]) {
-  float pq[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) pq[r] = Elem<T>::to_f32(Elem<T>::from_f32(e[r]));
-  return (pq[0] + pq[1]) + (pq[2] + pq[3]);
-}
-template <>
-__device__ __forceinline__ float round_sum4<BF16>(const float (&e)[4]) {
-  const uint32_t p01 = round_pack2<BF16>(e[0], e[1]);
-  const uint32_t p23 = round_pack2<BF16>(e[2], e[3]);
-  const f32x2 lo = {__uint_as_float(p01 << 16), __uint_as_float(p23 << 16)};
-  const f32x2 hi = {__uint_as_float(p01 & 0xffff0000u), __uint_as_float(p23 & 0xffff0000u)};
-  const f32x2 s = lo + hi;                                                 // (p0 + p1), (p2 + p3)
-  return s.x + s.y;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -106,14 +103,30 @@ struct Stager {                        // one thread's share of a 64 x 256 B til
   u32x4 v[4];
 };
 
-__device__ __forceinline__ void stage_load(Stager& st, const uint16_t* base, int64_t stride, int row0, int nrows, int tid) {
-  const int c = tid & 15, r0 = tid >> 4;
+// The streamed matrix of one head as a raw buffer.  Per thread one byte offset (row tid/16, chunk tid%16), computed
+// once; per tile the descriptor's base and extent move on the scalar unit; rows r0+16i come through the scalar offset.
+// A load that starts past `extent` returns 0, so the last tile needs no clamping.
+struct TileStream {
+  const uint16_t* base;                // row 0 of the head
+  int64_t stride_b;                    // bytes between rows
+  int nrows;
+  uint32_t voff;                       // this thread's byte offset inside a tile
+};
+__device__ __forceinline__ TileStream make_stream(const uint16_t* base, int64_t stride, int nrows, int tid) {
+  TileStream s;
+  s.base = base; s.stride_b = stride * 2; s.nrows = nrows;
+  s.voff = (uint32_t)(tid >> 4) * (uint32_t)s.stride_b + (uint32_t)(tid & 15) * 16u;
+  return s;
+}
+__device__ __forceinline__ void stage_load(Stager& st, const TileStream& s, int row0) {
+  const int left = s.nrows - row0;                                          // rows still inside the matrix (scalar)
+  const int64_t ext = left > 0 ? (int64_t)(left - 1) * s.stride_b + 256 : 0;
+  const uint32_t extent = ext > 0xffffffffll ? 0xffffffffu : (uint32_t)ext;
+  const char* tile = reinterpret_cast<const char*>(s.base) + (left > 0 ? (int64_t)row0 * s.stride_b : 0);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tile), 0, extent, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int r = row0 + r0 + 16 * i;
-    r = r < nrows ? r : nrows - 1;                                            // clamp: masked by the consumer
-    st.v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)r * stride + c * 8);
-  }
+  for (int i = 0; i < 4; ++i)
+    st.v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, s.voff, (uint32_t)(16 * i) * (uint32_t)s.stride_b, 0));
 }
 __device__ __forceinline__ void stage_store(const Stager& st, u32x4* tile, int tid) {
   const int c = tid & 15, r0 = tid >> 4;
@@ -133,6 +146,17 @@ __device__ __forceinline__ void load_frags(u32x4 (&f)[4], const uint16_t* base, 
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const u32x4*>(r + kk * 32);
 }
+// the 16 MFMAs of one 16-row sub-tile (fragments f, the A operand) against the wave's 64 resident rows (B): four
+// independent accumulators back to back, no dependent-MFMA stall.  D[streamed row][resident row].
+template <typename T>
+__device__ __forceinline__ void mm16(f32x4 (&acc)[4], const u32x4 (&f)[4], const u32x4 (&res)[4][4]) {
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = Mfma2<T>::run(f[kk], res[n][kk], acc[n]);
+}
 
 // Pass 1: per query row, max and sum of exp over all keys.  Resident = 256 query rows, streamed = K.
 // Per-lane online statistics (lane's column = one query, 4 keys per 16-key subtile); the running maximum
@@ -149,7 +173,6 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
   const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const int q0 = blockIdx.x * HWG + wave * HR;
   const float fmin_v = Elem<T>::finfo_min();
-  const bool corner_wave = q0 + HR > L;          // this wave holds observation-window rows (wave-uniform)
 
   u32x4 qf[4][4];
   int qi[4];
@@ -163,28 +186,30 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
 #pragma unroll
   for (int n = 0; n < 4; ++n) { m[n] = -INFINITY; mL[n] = 0.f; Z[n] = 0.f; }
 
+  const TileStream ks = make_stream(kb, p.ks_s, S, tid);
   Stager stg;
-  stage_load(stg, kb, p.ks_s, 0, S, tid);
+  stage_load(stg, ks, 0);
   stage_store(stg, tiles[0], tid);
   __syncthreads();
   const int ntiles = (S + HT - 1) / HT;
-  for (int t = 0; t < ntiles; ++t) {
+  // tiles that touch the end of the row or the masked corner run the EDGE instance of the body; all others carry no
+  // masking code at all
+  auto tile_body = [&](const int t, auto edge_tag) {
+    constexpr bool edge = decltype(edge_tag)::value;
     const int s_tile = t * HT;
     const u32x4* cur = tiles[t & 1];
-    if (t + 1 < ntiles) stage_load(stg, kb, p.ks_s, s_tile + HT, S, tid);     // in flight during the compute below
-    const bool edge = (s_tile + HT > S) || (corner_wave && s_tile + HT > L);  // wave-uniform: tail / masked corner
+    stage_load(stg, ks, s_tile + HT);                                         // in flight during the compute below; past the end: zeros
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       u32x4 kf[4];
       read_frags(kf, cur, sub, li, lg);
       const int s0 = s_tile + sub * 16;
+      f32x4 accs[4];
+      mm16<T>(accs, kf, qf);                                                  // D[key][query]
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = Mfma2<T>::run(kf[kk], qf[n][kk], acc);
         float x[4];
-        logits4<T>(acc, p, x);
+        logits4<T>(accs[n], p, x);
         if (edge) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -194,23 +219,26 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
             if (s >= S) x[r] = -INFINITY;
           }
         }
-        const float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        const float mx = max3_raw(max3_raw(x[0], x[1], x[2]), x[3], m[n]);
         if (__any(mx > m[n])) {                                               // rare once the maxima settle
           const float mn = fmaxf(m[n], mx);
           Z[n] = (m[n] == -INFINITY) ? 0.f : Z[n] * __builtin_amdgcn_exp2f((m[n] - mn) * L2E);
           m[n] = mn;
           mL[n] = (mn == -INFINITY) ? 0.f : -mn * L2E;
         }
-        const f32x2 c2 = {mL[n], mL[n]}, l2 = {L2E, L2E};
-        const f32x2 y01 = __builtin_elementwise_fma(f32x2{x[0], x[1]}, l2, c2);
-        const f32x2 y23 = __builtin_elementwise_fma(f32x2{x[2], x[3]}, l2, c2);
-        Z[n] += (__builtin_amdgcn_exp2f(y01.x) + __builtin_amdgcn_exp2f(y01.y)) +
-                (__builtin_amdgcn_exp2f(y23.x) + __builtin_amdgcn_exp2f(y23.y));
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(x[r], L2E, mL[n]);
+        Z[n] += (__builtin_amdgcn_exp2f(y[0]) + __builtin_amdgcn_exp2f(y[1])) +
+                (__builtin_amdgcn_exp2f(y[2]) + __builtin_amdgcn_exp2f(y[3]));
       }
     }
-    if (t + 1 < ntiles) stage_store(stg, tiles[(t + 1) & 1], tid);            // buffer last read in iteration t-1
+    stage_store(stg, tiles[(t + 1) & 1], tid);                                // buffer last read in iteration t-1
     __syncthreads();
-  }
+  };
+  const int t_plain = (L < S ? L : S) / HT;                                   // tiles [0, t_plain) end at or before L
+  for (int t = 0; t < t_plain; ++t) tile_body(t, std::false_type{});
+  for (int t = t_plain; t < ntiles; ++t) tile_body(t, std::true_type{});
   float2* rs = p.rowstat + (int64_t)bh * S;
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
@@ -229,11 +257,11 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
 }
 
 // Pass 2: per key column, sum over all query rows of round(exp(x - m) / Z).  Resident = 256 key columns,
-// streamed = Q (+ the 64 row statistics of the tile).
+// streamed = Q (+ the 64 row constants c_row of the tile).  No branch in the loop.
 template <typename T>
 __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
   __shared__ __attribute__((aligned(16))) u32x4 tiles[2][HT * 16];
-  __shared__ float2 stats[2][HT];
+  __shared__ __attribute__((aligned(16))) float stats[2][HT];             // c_row of the 64 streamed query rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y;
@@ -251,67 +279,61 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
     kj[n] = k0 + n * 16 + li;
     load_frags(kf[n], kb, kj[n] < S ? kj[n] : S - 1, p.ks_s, lg);
   }
-  float col[4] = {0.f, 0.f, 0.f, 0.f};
+  // matrix-pipe column sums (see the header): every row of cacc[n] holds the sums of key columns kj[n]
+  f32x4 cacc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) cacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = {Ones2<T>::v, Ones2<T>::v, Ones2<T>::v, Ones2<T>::v};
+  uint32_t held[4][2];
   const float L2E2 = 1.44269504088896340736f;
+  auto row_const = [&](int i) {                                // rows past S: exp2(x*log2e - inf) = 0 (clamped load + select: no branch)
+    const float c = rs[i < S ? i : S - 1].x;
+    return i < S ? c : -INFINITY;
+  };
 
+  const TileStream qs = make_stream(qb, p.qs_s, S, tid);
   Stager stg;
-  float2 sreg = make_float2(0.f, 0.f);
-  stage_load(stg, qb, p.qs_s, 0, S, tid);
-  if (tid < HT) sreg = rs[tid < S ? tid : S - 1];
+  stage_load(stg, qs, 0);
+  float sreg = row_const(lane);                                // all four waves carry the same 64 constants: no divergent branch
   stage_store(stg, tiles[0], tid);
-  if (tid < HT) stats[0][tid] = sreg;
+  stats[0][lane] = sreg;
   __syncthreads();
   const int ntiles = (S + HT - 1) / HT;
   for (int t = 0; t < ntiles; ++t) {
-    const int i_tile = t * HT;
     const u32x4* cur = tiles[t & 1];
-    const float2* cst = stats[t & 1];
-    if (t + 1 < ntiles) {
-      stage_load(stg, qb, p.qs_s, i_tile + HT, S, tid);
-      if (tid < HT) { const int i = i_tile + HT + tid; sreg = rs[i < S ? i : S - 1]; }
-    }
-    const bool tail = i_tile + HT > S;                                        // wave-uniform
+    const float* cst = stats[t & 1];
+    stage_load(stg, qs, (t + 1) * HT);                         // past the end: zeros (and c_row = -inf)
+    sreg = row_const((t + 1) * HT + lane);
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       u32x4 qf[4];
       read_frags(qf, cur, sub, li, lg);
-      float2 st[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) st[r] = cst[sub * 16 + lg * 4 + r];
-      const int i0 = i_tile + sub * 16;
+      const f32x4 st = *reinterpret_cast<const f32x4*>(cst + sub * 16 + lg * 4);
+      f32x4 accs[4];
+      mm16<T>(accs, qf, kf);                                   // D[query][key]
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = Mfma2<T>::run(qf[kk], kf[n][kk], acc);   // D[query][key]
         float x[4], e[4];
-        logits4<T>(acc, p, x);                                 // keys < L never touch the masked corner
-        const f32x2 l2 = {L2E2, L2E2};
-        const f32x2 y01 = __builtin_elementwise_fma(f32x2{x[0], x[1]}, l2, f32x2{st[0].x, st[1].x});
-        const f32x2 y23 = __builtin_elementwise_fma(f32x2{x[2], x[3]}, l2, f32x2{st[2].x, st[3].x});
-        e[0] = __builtin_amdgcn_exp2f(y01.x); e[1] = __builtin_amdgcn_exp2f(y01.y);   // fp32 softmax (:553): exp(x - m) / Z
-        e[2] = __builtin_amdgcn_exp2f(y23.x); e[3] = __builtin_amdgcn_exp2f(y23.y);
-        if (tail) {                                            // wave-uniform, last tile only: rows past S contribute 0
+        logits4<T>(accs[n], p, x);                             // keys < L never touch the masked corner
 #pragma unroll
-          for (int r = 0; r < 4; ++r) if (i0 + lg * 4 + r >= S) e[r] = 0.f;
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r], L2E2, st[r]));   // fp32 softmax (:553): exp(x - m) / Z
+        const uint32_t p01 = round_pack2<T>(e[0], e[1]), p23 = round_pack2<T>(e[2], e[3]);              // .to(dtype)
+        if ((sub & 1) == 0) {
+          held[n][0] = p01; held[n][1] = p23;
+        } else {                                               // this lane's 8 query rows of key column li; fp32 sum (:554)
+          const u32x4 pb = {held[n][0], held[n][1], p01, p23};
+          cacc[n] = Mfma2<T>::run(ones, pb, cacc[n]);
         }
-        col[n] += round_sum4<T>(e);                            // .to(dtype), sum over all rows in fp32 (:554)
       }
     }
-    if (t + 1 < ntiles) {
-      stage_store(stg, tiles[(t + 1) & 1], tid);
-      if (tid < HT) stats[(t + 1) & 1][tid] = sreg;
-    }
+    stage_store(stg, tiles[(t + 1) & 1], tid);
+    stats[(t + 1) & 1][lane] = sreg;
     __syncthreads();
   }
   uint16_t* out = reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride;
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    float c = col[n];
-    c += __shfl_xor(c, 16, 64);
-    c += __shfl_xor(c, 32, 64);
-    if (lg == 0 && kj[n] < L) out[kj[n]] = Elem<T>::from_f32(c);
-  }
+  for (int n = 0; n < 4; ++n)                                  // the MFMA already summed the four lane groups
+    if (lg == 0 && kj[n] < L) out[kj[n]] = Elem<T>::from_f32(cacc[n][0]);
 }
 
 template __global__ void h2o_stats_kernel<BF16>(H2OParams);
@@ -319,7 +341,13 @@ template __global__ void h2o_stats_kernel<F16>(H2OParams);
 template __global__ void h2o_colsum_kernel<BF16>(H2OParams);
 template __global__ void h2o_colsum_kernel<F16>(H2OParams);
 
+// raw-buffer tile loads carry 32-bit offsets: 64 rows of the streamed matrix must span less than 4 GB
+static bool strides_ok(const H2OParams& p) {
+  return p.qs_s > 0 && p.ks_s > 0 && p.qs_s * 2 * 64 < (int64_t)0xffffffffll && p.ks_s * 2 * 64 < (int64_t)0xffffffffll;
+}
+
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
+  if (!strides_ok(p)) return hipErrorInvalidValue;
   dim3 grid((p.S + HWG - 1) / HWG, p.B * p.H);
   if (dtype == 0) hipLaunchKernelGGL(h2o_stats_kernel<BF16>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(h2o_stats_kernel<F16>, grid, dim3(256), 0, st, p);
@@ -327,6 +355,7 @@ hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
 }
 
 hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st) {
+  if (!strides_ok(p)) return hipErrorInvalidValue;
   const int L = p.S - p.w;
   dim3 grid((L + HWG - 1) / HWG, p.B * p.H);
   if (dtype == 0) hipLaunchKernelGGL(h2o_colsum_kernel<BF16>, grid, dim3(256), 0, st, p);

@@ -141,7 +141,7 @@ if pb or ab:
     lines.append("")
 stats_table("prof_h2o", "H2O at S = 32768 (tools/h2o_only.py), rocprofv3 --kernel-trace --stats", 4)
 acc = defaultdict(lambda: defaultdict(list))
-for d in ("pmc_h2o_a", "pmc_h2o_b"):
+for d in ("pmc_h2o_a", "pmc_h2o_b", "pmc_h2o_c"):
     for f in glob.glob(os.path.join(G, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if "pkv::" in r["Kernel_Name"]:
@@ -154,6 +154,18 @@ if acc:
     for k, v in h2o.items():
         lines.append("| %s | " % k + " | ".join("%.4g" % v[c] for c in sorted(v)) + " |")
     lines.append("")
+    bf = os.path.join(P, "pmc_h2o_before.json")
+    if os.path.exists(bf):
+        b4 = json.load(open(bf))
+        lines += ["Before this round's H2O rework (`pmc_h2o_before.json`, same command on commit d56ac47) -> now:\n", "| kernel | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_BUSY_CYCLES |", "|---|---|---|---|"]
+        for k in h2o:
+            if k in b4:
+                lines.append("| %s | " % k + " | ".join("%.4g -> %.4g" % (b4[k][c], h2o[k][c]) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES")) + " |")
+        lines.append("")
+hab = os.path.join(G, "h2o_ab.txt")
+if os.path.exists(hab):
+    shutil.copy(hab, os.path.join(P, "h2o_ab.txt"))
+    lines += ["## H2O kernels before / after, same box (tools/r02_h2o_ab.sh; us per launch, S = 32768, H = 32)\n", "```", open(hab).read().strip(), "```", ""]
 bw = os.path.join(G, "bw_probe.json")
 if os.path.exists(bw):
     lines += ["## Achievable HBM bandwidth on this box (tools/bw_probe.hip, 1 GiB)\n", "```", open(bw).read().strip(), "```", ""]
