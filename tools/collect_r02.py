@@ -142,7 +142,7 @@ if pb or ab:
 stats_table("prof_h2o", "H2O at S = 32768 (tools/h2o_only.py), rocprofv3 --kernel-trace --stats", 4)
 acc = defaultdict(lambda: defaultdict(list))
 for d in ("pmc_h2o_a", "pmc_h2o_b", "pmc_h2o_c"):
-    for f in glob.glob(os.path.join(G, d, "**", "*counter_collection.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(G, d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:   # newest run only: gpurun merges, never cleans
         for r in csv.DictReader(open(f)):
             if "pkv::" in r["Kernel_Name"]:
                 acc[r["Kernel_Name"].split("pkv::")[1].split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))

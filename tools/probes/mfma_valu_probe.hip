@@ -13,6 +13,7 @@ template <int KIND> __device__ __forceinline__ void filler(float& a, float b) {
   if constexpr (KIND == 0) asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(a) : "v"(b));
   if constexpr (KIND == 1) asm volatile("v_cvt_pk_bf16_f32 %0, 0, %0" : "+v"(a));
   if constexpr (KIND == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(a));
+  if constexpr (KIND == 4) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(b));
 }
 
 template <int MF, int NV, int KIND>
@@ -25,6 +26,9 @@ __global__ __launch_bounds__(512) void probe(float* out, uint64_t* cyc, int iter
   float v[8];
   for (int i = 0; i < 8; ++i) v[i] = 0.001f * (lane + i);
   const float bb = 1.0001f;
+  typedef float f32x2p __attribute__((ext_vector_type(2)));
+  f32x2p pk[4], pkb = {1.0001f, 0.9999f};
+  for (int i = 0; i < 4; ++i) pk[i] = f32x2p{0.001f * lane, 0.002f * i};
   const uint64_t t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -35,7 +39,10 @@ __global__ __launch_bounds__(512) void probe(float* out, uint64_t* cyc, int iter
       if constexpr (MF == 3) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c16[u & 1]) : "v"(a), "v"(b));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int k = 0; k < NV; ++k) filler<KIND>(v[(u * NV + k) & 7], bb);
+      for (int k = 0; k < NV; ++k) {
+        if constexpr (KIND == 3) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(pk[(u * NV + k) & 3]) : "v"(pkb));   // 2 fp32 FMAs per instruction
+        else filler<KIND>(v[(u * NV + k) & 7], bb);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -44,6 +51,7 @@ __global__ __launch_bounds__(512) void probe(float* out, uint64_t* cyc, int iter
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) s += c4[i][j];
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 16; ++j) s += c16[i][j];
   for (int i = 0; i < 8; ++i) s += v[i];
+  for (int i = 0; i < 4; ++i) s += pk[i].x + pk[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
@@ -78,6 +86,12 @@ template <int MF, int KIND> void sweep(float* out, uint64_t* cyc) {
 int main() {
   float* out; uint64_t* cyc;
   hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 8);
+  if (getenv("PROBE_NOMFMA")) {   // vector instructions alone (MF = 4: no MFMA in the group): plain fma, packed fma, exp2, integer multiply
+    run<4, 8, 0>(1, out, cyc); run<4, 8, 0>(2, out, cyc); run<4, 8, 3>(1, out, cyc); run<4, 8, 3>(2, out, cyc);
+    run<4, 8, 2>(1, out, cyc); run<4, 8, 2>(2, out, cyc); run<4, 8, 4>(1, out, cyc); run<4, 8, 4>(2, out, cyc);
+    run<0, 4, 3>(2, out, cyc); run<1, 6, 3>(2, out, cyc);
+    return 0;
+  }
   if (getenv("PROBE_AGPR")) { sweep<2, 0>(out, cyc); sweep<3, 0>(out, cyc); return 0; }
   sweep<0, 0>(out, cyc); sweep<1, 0>(out, cyc);
   sweep<0, 1>(out, cyc); sweep<0, 2>(out, cyc);

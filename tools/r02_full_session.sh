@@ -6,8 +6,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/full
 rm -rf $O; mkdir -p $O
 cd $R
+if [ -z "${SKIP_PYTEST:-}" ]; then   # SKIP_PYTEST=1: the suite ran in its own gpurun call (gpurun_out/full/pytest.txt is kept)
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 --durations=5 > $O/pytest.txt 2>&1
 echo "pytest exit $?" >> $O/pytest.txt
+fi
 cp gpurun_out/parity_report.json $O/parity_report.json 2>/dev/null
 ./tools/bw_probe > $O/bw_probe.json 2> $O/bw_probe.err
 # the driver's command
@@ -39,6 +41,6 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIV
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_h2o_b -- python $R/tools/h2o_only.py 32768 > $O/pmc_h2o_b.log 2>&1
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_h2o_c -- python $R/tools/h2o_only.py 32768 > $O/pmc_h2o_c.log 2>&1
 # the H2O kernels of the parent commit d56ac47 (tools/_h2o_base.so, built by hand) against the current ones, same box
-bash $R/tools/r02_h2o_ab.sh > $O/h2o_ab.log 2>&1
+(cd $R && bash tools/r02_h2o_ab.sh) > $O/h2o_ab.log 2>&1
 cd $R
 tail -4 $O/pytest.txt; head -c 400 $O/bench.json; echo; tail -2 $O/bench.err
