@@ -32,7 +32,7 @@ typedef void* pkv_stream_t; /* hipStream_t */
 
 enum pkv_status {
   PKV_OK = 0,
-  PKV_ERR_DTYPE = -1,       /* dtype not bf16/fp16 */
+  PKV_ERR_DTYPE = -1,       /* dtype not bf16 / fp16 / fp32 */
   PKV_ERR_SHAPE = -2,       /* D not in {64,128,256}, window/topk out of range, k > L ... */
   PKV_ERR_ALIGN = -3,       /* pointer or stride breaks 16-byte row alignment */
   PKV_ERR_WORKSPACE = -4,   /* workspace too small */
@@ -42,7 +42,9 @@ enum pkv_status {
   PKV_ERR_COLLECTIVE = -8   /* an RCCL call failed; see pkv_last_nccl_error() */
 };
 
-enum pkv_dtype { PKV_BF16 = 0, PKV_F16 = 1 };
+/* PKV_F32: pkv_score_window, pkv_topk(_ws), pkv_gather_compact, pkv_gather_streaming, pkv_compress and pkv_select
+ * (window score) only, D in {64,128}, topk <= 4096; every other entry point answers PKV_ERR_UNSUPPORTED. */
+enum pkv_dtype { PKV_BF16 = 0, PKV_F16 = 1, PKV_F32 = 2 };
 enum pkv_pool { PKV_POOL_NONE = 0, PKV_POOL_AVG = 1, PKV_POOL_MAX = 2 };
 enum pkv_reduce { PKV_REDUCE_SUM = 0, PKV_REDUCE_MEAN = 1 };
 /* how A/sqrt(D) is evaluated (pyramidkv_utils.py:317): DIV = fp32 division (ATen CPU),

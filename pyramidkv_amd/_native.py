@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PKV_LIB selects another build of the same ABI (tools/ load libpkv_debug.so, the -DPKV_DEBUG build with trace hooks)
 LIB_PATH = os.environ.get("PKV_LIB") or os.path.join(_HERE, "libpkv.so")
 
-PKV_BF16, PKV_F16 = 0, 1
+PKV_BF16, PKV_F16, PKV_F32 = 0, 1, 2
 POOL = {None: 0, "none": 0, "avgpool": 1, "maxpool": 2}
 REDUCE = {"sum": 0, "mean": 1}
 SCALE = {"div": 0, "rcp": 1}
@@ -107,7 +107,9 @@ def dtype_code(dt: torch.dtype) -> int:
         return PKV_BF16
     if dt == torch.float16:
         return PKV_F16
-    raise ValueError(f"pyramidkv_amd supports bf16/fp16 tensors, got {dt}")
+    if dt == torch.float32:      # window policies + StreamingLLM only (include/pkv.h: PKV_F32); the rest raises ValueError
+        return PKV_F32
+    raise ValueError(f"pyramidkv_amd supports bf16/fp16/fp32 tensors, got {dt}")
 
 
 def stream_ptr() -> int:

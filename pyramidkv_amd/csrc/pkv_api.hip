@@ -87,10 +87,13 @@ struct ProfScope {
 };
 
 // ---- validation ------------------------------------------------------------------------------
-int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true) {
+// f32_ok: the entry point has an fp32 path (window scores, top-k, dense / streaming gather); every other one answers
+// PKV_ERR_UNSUPPORTED for fp32 tensors
+int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true, bool f32_ok = false) {
   if (!d) return PKV_ERR_NULL;
-  if (d->dtype != PKV_BF16 && d->dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (d->dtype != PKV_BF16 && d->dtype != PKV_F16 && d->dtype != PKV_F32) return PKV_ERR_DTYPE;
   if (d->D != 64 && d->D != 128 && d->D != 256) return PKV_ERR_SHAPE;      // H2O and the merge: 128 only (checked there)
+  if (d->dtype == PKV_F32 && (!f32_ok || d->D == 256)) return PKV_ERR_UNSUPPORTED;
   if (d->B < 1 || d->H < 1 || d->S < 2) return PKV_ERR_SHAPE;
   if (d->kv_group < 1 || d->H % d->kv_group) return PKV_ERR_SHAPE;
   if (d->window < 1 || d->window >= d->S) return PKV_ERR_SHAPE;
@@ -101,9 +104,11 @@ int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true) {
     if (d->pool_kernel < 1 || !(d->pool_kernel & 1)) return PKV_ERR_SHAPE;
     if (d->pool_kernel > 17) return PKV_ERR_UNSUPPORTED;
   }
+  const int64_t amask = d->dtype == PKV_F32 ? 3 : 7;                       // rows start on 16-byte boundaries
   for (int i = 0; i < 3; ++i)
-    if ((d->q_stride[i] & 7) || (d->k_stride[i] & 7) || (d->v_stride[i] & 7)) return PKV_ERR_ALIGN;
+    if ((d->q_stride[i] & amask) || (d->k_stride[i] & amask) || (d->v_stride[i] & amask)) return PKV_ERR_ALIGN;
   if ((int64_t)d->B * d->H > 65535) return PKV_ERR_UNSUPPORTED;
+  if (d->dtype == PKV_F32 && need_topk && d->topk > topk_f32_max_k()) return PKV_ERR_UNSUPPORTED;
   return PKV_OK;
 }
 
@@ -120,10 +125,12 @@ WsLayout ws_layout(const pkv_desc* d) {
   w.Sp = (d->S + 255) / 256 * 256;
   w.Lp = (int)align_up((size_t)(d->S - d->window), 8);
   const size_t rows = (size_t)d->B * d->H * d->window;
+  const size_t es = d->dtype == PKV_F32 ? 4 : 2;                            // bytes per logit / score
+  if (d->dtype == PKV_F32) w.nT = (d->S + 63) / 64;                         // logits_f32_kernel: 64 keys per workgroup
   size_t o = 0;
-  w.off_logits = o;  o = align_up(o + rows * w.Sp * 2, 256);
+  w.off_logits = o;  o = align_up(o + rows * w.Sp * es, 256);
   w.off_partial = o; o = align_up(o + rows * (size_t)std::max(w.nT, (d->S + 127) / 128) * sizeof(float2), 256);
-  w.off_scores = o;  o = align_up(o + (size_t)d->B * d->H * w.Lp * 2, 256);
+  w.off_scores = o;  o = align_up(o + (size_t)d->B * d->H * w.Lp * es, 256);
   w.off_idx = o;     o = align_up(o + (size_t)d->B * d->H * (d->topk > 0 ? d->topk : 1) * 4, 256);
   w.off_cmax = o;    o = align_up(o + (size_t)d->B * d->H * (w.Lp / 8) * 2, 256);
   w.tk_bytes = d->topk > 0 ? topk_tmp_bytes(d->B * d->H, d->S - d->window, d->topk) : 0;      // long-row top-k scratch (0 up to 57 344 keys)
@@ -151,6 +158,25 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   lp.rcp_sqrt_d = 1.0f / lp.sqrt_d;        // ATen GPU path: a * (1.0f / b)
   const int C = d->kv_group * d->window;
   int nT_used = L.nT;
+  if (d->dtype == PKV_F32) {
+    lp.nT = L.nT;
+    {
+      ProfScope ps(PKV_K_LOGITS, st, true);
+      hipError_t e = launch_logits_f32(lp, st);
+      if (e != hipSuccess) return hip_fail(e);
+    }
+    FinalizeParams fp;
+    fp.logits = lp.logits; fp.partial = lp.partial;
+    fp.scores = scores; fp.scores_stride = stride;
+    fp.B = d->B; fp.H = d->H; fp.S = d->S; fp.w = d->window; fp.Sp = L.Sp; fp.nT = L.nT;
+    fp.pool_kind = d->pool_kind;
+    fp.pool_kernel = d->pool_kind == PKV_POOL_NONE ? 1 : d->pool_kernel;
+    fp.reduce = d->reduce;
+    fp.cmax = nullptr; fp.cmax_stride = 0; fp.trace = nullptr; fp.wgtrace = nullptr;
+    ProfScope ps(PKV_K_FINALIZE, st, true);
+    hipError_t e = launch_finalize_f32(fp, st);
+    return e == hipSuccess ? PKV_OK : hip_fail(e);
+  }
   if (logits_v2() && C <= 32 && d->D == 128 && !g_wg_trace) {
     static int cus = 0;
     if (!cus) {
@@ -246,6 +272,12 @@ int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t strid
   tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
   tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace; tp.wgtrace = g_wg_trace; tp.cmax = cmax; tp.cmax_stride = cmax_stride;
   tp.nseg = 1; tp.seg_len = 0; tp.algo = topk_algo();
+  if (dtype == PKV_F32) {                                  // radix select on 32-bit keys (pkv_f32.hip); k_per_row <= k
+    if (k > topk_f32_max_k()) return PKV_ERR_UNSUPPORTED;
+    ProfScope ps(PKV_K_TOPK, st, true);
+    hipError_t e = launch_topk_f32(rows, tp, st);
+    return e == hipSuccess ? PKV_OK : hip_fail(e);
+  }
   auto launch = [&](int nrows, int Lwg) -> int {     // Lwg = keys one workgroup handles
     const size_t lds = topk_lds_bytes(Lwg, tp.k, &tp.Lw, &tp.kpad);
     if (lds > 160 * 1024 || 16 * (size_t)tp.Lw > 65536) return PKV_ERR_UNSUPPORTED;
@@ -288,6 +320,10 @@ GatherParams make_gather(const pkv_desc* d, const void* k, const void* v, void* 
   g.B = d->B; g.H = d->H; g.S = d->S; g.w = d->window; g.nsel = d->topk; g.G = d->kv_group; g.D = d->D;
   g.ks_b = d->k_stride[0]; g.ks_h = d->k_stride[1]; g.ks_s = d->k_stride[2];
   g.vs_b = d->v_stride[0]; g.vs_h = d->v_stride[1]; g.vs_s = d->v_stride[2];
+  if (d->dtype == PKV_F32) {            // the copy kernels move 16-byte pieces: [.., D] fp32 is [.., 2D] 16-bit with doubled strides
+    g.D = 2 * d->D;
+    g.ks_b *= 2; g.ks_h *= 2; g.ks_s *= 2; g.vs_b *= 2; g.vs_h *= 2; g.vs_s *= 2;
+  }
   return g;
 }
 
@@ -299,7 +335,7 @@ int do_gather(const GatherParams& g, int max_rows, hipStream_t st) {
 
 int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
                     void* v_out, int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
-  int rc = check_desc(d, true);
+  int rc = check_desc(d, true, true, !h2o);
   if (rc) return rc;
   if (!q || !k || !v || !k_out || !v_out || !ws) return PKV_ERR_NULL;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out) || misaligned(ws))
@@ -309,7 +345,7 @@ int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* w = static_cast<char*>(ws);
   void* scores = w + L.off_scores;
-  const bool cm = !h2o && env_int("PKV_TOPK_CMAX", 1) != 0;   // chunk maxima feed the top-k prefilter
+  const bool cm = !h2o && d->dtype != PKV_F32 && env_int("PKV_TOPK_CMAX", 1) != 0;   // chunk maxima feed the top-k prefilter
   if (h2o && d->D != 128) return PKV_ERR_UNSUPPORTED;
   rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
@@ -354,7 +390,7 @@ size_t pkv_workspace_bytes(const pkv_desc* d) {
 
 int pkv_score_window(const pkv_desc* d, const void* q, const void* k, void* scores_out,
                      int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream) {
-  int rc = check_desc(d, false);
+  int rc = check_desc(d, false, true, true);
   if (rc) return rc;
   if (!q || !k || !scores_out || !ws) return PKV_ERR_NULL;
   if (misaligned(q) || misaligned(k) || misaligned(scores_out) || misaligned(ws)) return PKV_ERR_ALIGN;
@@ -379,7 +415,7 @@ int pkv_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores_
 
 int pkv_topk(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores, int64_t scores_stride,
              const int32_t* k_per_row, int32_t* idx_out, int64_t idx_stride, pkv_stream_t stream) {
-  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (dtype != PKV_BF16 && dtype != PKV_F16 && dtype != PKV_F32) return PKV_ERR_DTYPE;
   if (!scores || !idx_out) return PKV_ERR_NULL;
   if (scores_stride < L || idx_stride < k) return PKV_ERR_SHAPE;
   return do_topk(dtype, rows, L, k, scores, scores_stride, k_per_row, idx_out, idx_stride, static_cast<hipStream_t>(stream));
@@ -390,17 +426,17 @@ size_t pkv_topk_workspace_bytes(int32_t rows, int32_t L, int32_t k) { return top
 int pkv_topk_ws(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores, int64_t scores_stride,
                 const int32_t* k_per_row, int32_t* idx_out, int64_t idx_stride, void* ws, size_t ws_bytes,
                 pkv_stream_t stream) {
-  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (dtype != PKV_BF16 && dtype != PKV_F16 && dtype != PKV_F32) return PKV_ERR_DTYPE;
   if (!scores || !idx_out) return PKV_ERR_NULL;
   if (scores_stride < L || idx_stride < k) return PKV_ERR_SHAPE;
-  if (topk_tmp_bytes(rows, L, k) > 0 && (!ws || ws_bytes < topk_tmp_bytes(rows, L, k))) return PKV_ERR_WORKSPACE;
+  if (dtype != PKV_F32 && topk_tmp_bytes(rows, L, k) > 0 && (!ws || ws_bytes < topk_tmp_bytes(rows, L, k))) return PKV_ERR_WORKSPACE;
   return do_topk(dtype, rows, L, k, scores, scores_stride, k_per_row, idx_out, idx_stride, static_cast<hipStream_t>(stream),
                  nullptr, 0, ws, ws_bytes);
 }
 
 int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx,
                        int64_t idx_stride, void* k_out, void* v_out, pkv_stream_t stream) {
-  int rc = check_desc(d, true, false);
+  int rc = check_desc(d, true, false, true);
   if (rc) return rc;
   if (!k || !v || !idx || !k_out || !v_out) return PKV_ERR_NULL;
   if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out)) return PKV_ERR_ALIGN;
@@ -412,7 +448,7 @@ int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const in
 
 int pkv_gather_streaming(const pkv_desc* d, const void* k, const void* v, void* k_out, void* v_out,
                          pkv_stream_t stream) {
-  int rc = check_desc(d, true, false);
+  int rc = check_desc(d, true, false, true);
   if (rc) return rc;
   if (!k || !v || !k_out || !v_out) return PKV_ERR_NULL;
   if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out)) return PKV_ERR_ALIGN;
@@ -433,7 +469,7 @@ int pkv_compress_h2o(const pkv_desc* d, const void* q, const void* k, const void
 // ---- selection only (score -> top-k), the front half of pkv_compress: what the merge path needs ----
 int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int32_t* idx_out, void* ws, size_t ws_bytes,
                pkv_stream_t stream) {
-  int rc = check_desc(d, true);
+  int rc = check_desc(d, true, true, !h2o);
   if (rc) return rc;
   if (!q || !k || !idx_out || !ws) return PKV_ERR_NULL;
   if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
@@ -443,7 +479,7 @@ int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* w = static_cast<char*>(ws);
   void* scores = w + L.off_scores;
-  const bool cm = !h2o && env_int("PKV_TOPK_CMAX", 1) != 0;
+  const bool cm = !h2o && d->dtype != PKV_F32 && env_int("PKV_TOPK_CMAX", 1) != 0;
   rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
   return do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx_out, d->topk, st,

@@ -1,0 +1,345 @@
+// pkv_f32.hip — the window-score / top-k path for fp32 tensors (gfx950).
+//
+// The reference is dtype-generic (pyramidkv_utils.py:317-346 on fp32 tensors: fp32 matmul, fp32 softmax, no intermediate
+// rounding); real models hand over bf16 / fp16, so this path is built for completeness and correctness, HBM-bound like the
+// 16-bit one but not tuned to the same degree:
+//   logits_f32_kernel    :317-324  Q[-w:] K^T / sqrt(D) on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate),
+//                                  causal corner mask, per-tile (max, sum exp) partials
+//   finalize_f32_kernel  :326-331  softmax over all S keys, sum / mean of the window rows, avg / max pool
+//   topk_f32_kernel      :334      k largest of a row in (value desc, index asc) order: 4 x 8-bit radix select on the
+//                                  order-preserving 32-bit keys, ties by position, bitonic sort of the k winners in LDS
+// The gather needs no fp32 kernel: a [.., D] fp32 tensor is a [.., 2D] 16-bit tensor with doubled strides (pkv_api.hip).
+// fp32 sums whose order is not pinned by the reference (the D-long dot product, the softmax denominator) differ from ATen's
+// CPU kernels in the last bits; tests compare scores with a relative tolerance and selections up to score ties within it.
+#include "pkv_common.hpp"
+#include "pkv_kernels.hpp"
+
+namespace pkv {
+
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+
+// ------------------------------------------------------------------------------------------------
+// logits_f32_kernel: one workgroup = 64 keys of one (batch, kv-head group), 16 keys per wave; the C = G*w query rows of
+// the group in tiles of 16 columns.  MFMA 16x16x4 f32: A = keys (row l%16, k-slot l/16), B = queries (column l%16,
+// k-slot l/16).  Every lane loads float4 pieces (columns 16j + 4*(l/16) .. +3 of its row), so MFMA number 4j+i multiplies
+// element 16j + 4*(l/16) + i of both operands: the dot product's terms are all there, in a permuted order.
+// ------------------------------------------------------------------------------------------------
+template <int KS>                                   // float4 pieces per lane and row: D / 16
+__global__ __launch_bounds__(256) void logits_f32_kernel(LogitsParams p) {
+  __shared__ float2 wst[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int tile = blockIdx.x, grp = blockIdx.y;
+  const int HG = p.H / p.G;
+  const int b = grp / HG, hk = grp - b * HG, h0 = hk * p.G;
+  const int w = p.w, C = p.G * w, S = p.S, L = S - w;
+  const int s_wave = tile * 64 + wave * 16;
+  const float* kb = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
+  const float* qb = reinterpret_cast<const float*>(p.q) + (int64_t)b * p.qs_b;
+  const int64_t rowbase = ((int64_t)b * p.H + h0) * w;
+  float* lg_out = reinterpret_cast<float*>(p.logits);
+  const float fmin_v = -3.4028234663852886e38f;    // torch.finfo(torch.float32).min
+
+  f32x4 kf[KS];
+  {
+    const int s = s_wave + li;
+    const float* kr = kb + (int64_t)(s < S ? s : S - 1) * p.ks_s + 4 * lg;       // clamp: keys past S are masked below
+#pragma unroll
+    for (int j = 0; j < KS; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kr + 16 * j);
+  }
+  const int nct = (C + 15) / 16;
+  for (int n = 0; n < nct; ++n) {
+    const int c = n * 16 + li;
+    const int cc = c < C ? c : C - 1;
+    const int hh = h0 + cc / w, rr = cc - (cc / w) * w;
+    const float* qr = qb + (int64_t)hh * p.qs_h + (int64_t)(L + rr) * p.qs_s + 4 * lg;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(qr + 16 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][i], qv[i], acc, 0, 0, 0);
+    }
+    // lane (li, lg): column c, keys s_wave + 4*lg + r
+    float x[4];
+    float m4 = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = s_wave + 4 * lg + r;
+      float v = p.scale_mode == 0 ? div_const(acc[r], p.sqrt_d, p.rcp_sqrt_d) : acc[r] * p.rcp_sqrt_d;   // / math.sqrt(head_dim) (:317)
+      if (s >= L && (s - L) > rr) v = v + fmin_v;                                                          // strict upper corner (:318-324)
+      x[r] = v;
+      if (s < S) m4 = fmaxf(m4, v);
+    }
+    if (c < C && s_wave + 4 * lg < S)                 // Sp is a multiple of 256: the 4 floats are in bounds
+      *reinterpret_cast<f32x4*>(lg_out + (rowbase + c) * (int64_t)p.Sp + s_wave + 4 * lg) = f32x4{x[0], x[1], x[2], x[3]};
+    float l4 = 0.f;
+    const float ms = (m4 == -INFINITY) ? 0.f : m4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (s_wave + 4 * lg + r < S) l4 += pkv_exp(x[r] - ms);
+    // merge the four key groups of the wave, then the four waves
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float mo = __shfl_xor(m4, o, 64), lo = __shfl_xor(l4, o, 64);
+      const float M = fmaxf(m4, mo), Ms = (M == -INFINITY) ? 0.f : M;
+      l4 = l4 * pkv_exp(m4 - Ms) + lo * pkv_exp(mo - Ms);
+      m4 = M;
+    }
+    __syncthreads();                                   // wst of the previous column tile has been read
+    if (lg == 0) wst[wave][li] = make_float2(m4, l4);
+    __syncthreads();
+    if (tid < 16 && n * 16 + tid < C) {
+      float2 a = wst[0][tid];
+#pragma unroll
+      for (int wv = 1; wv < 4; ++wv) {
+        const float2 o = wst[wv][tid];
+        const float M = fmaxf(a.x, o.x), Ms = (M == -INFINITY) ? 0.f : M;
+        a.y = a.y * pkv_exp(a.x - Ms) + o.y * pkv_exp(o.x - Ms);
+        a.x = M;
+      }
+      p.partial[(rowbase + n * 16 + tid) * p.nT + tile] = a;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize_f32_kernel: one workgroup = 1008 output positions (+8 halo each side) of one (b,h), 256 threads x 4 positions.
+// ------------------------------------------------------------------------------------------------
+constexpr int F32_SPAN = 1024, F32_OUT = F32_SPAN - 16;
+
+__global__ __launch_bounds__(256) void finalize_f32_kernel(FinalizeParams p) {
+  __shared__ __attribute__((aligned(16))) float sc[F32_SPAN];
+  __shared__ float rowM[64], rowS[64];
+  const int tid = threadIdx.x, bh = blockIdx.y;
+  const int w = p.w, L = p.S - w;
+  const int64_t rowbase = (int64_t)bh * w;
+  // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M); 32 lanes per row
+  {
+    const int sub = tid & 31;
+    for (int r0 = 0; r0 < w; r0 += 8) {
+      const int r = r0 + (tid >> 5);
+      const bool live = r < w;
+      const float2* pr = p.partial + (rowbase + (live ? r : 0)) * p.nT;
+      float m = -INFINITY, z = 0.f;
+      for (int t = sub; t < p.nT; t += 32) {
+        const float2 pv = pr[t];
+        const float mn = fmaxf(m, pv.x);
+        if (mn != -INFINITY) z = z * pkv_exp(m - mn) + pv.y * pkv_exp(pv.x - mn);
+        m = mn;
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float mo = __shfl_xor(m, o, 64), zo = __shfl_xor(z, o, 64);
+        const float mn = fmaxf(m, mo);
+        if (mn != -INFINITY) z = z * pkv_exp(m - mn) + zo * pkv_exp(mo - mn);
+        m = mn;
+      }
+      if (live && sub == 0) { rowM[r] = m; rowS[r] = 1.0f / z; }     // ATen CPU softmax: exp(x - max) * (1 / sum)
+    }
+  }
+  __syncthreads();
+  const int s0 = blockIdx.x * F32_OUT - 8 + tid * 4;
+  const float pad = (p.pool_kind == 2) ? -INFINITY : 0.f;
+  float ov[4] = {pad, pad, pad, pad};
+  if (s0 >= 0 && s0 < L) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* lgp = reinterpret_cast<const float*>(p.logits) + rowbase * (int64_t)p.Sp + s0;
+    for (int r = 0; r < w; ++r) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(lgp + (int64_t)r * p.Sp);
+      const float M = rowM[r], RZ = rowS[r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += pkv_exp(u[e] - M) * RZ;           // fp32 softmax (:326), rows added in order (:327)
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = (p.reduce == 1) ? (acc[e] / (float)w) : acc[e];         // mean (:661) or sum (:327)
+      if (s0 + e < L) ov[e] = v;
+    }
+  }
+  *reinterpret_cast<f32x4*>(sc + tid * 4) = f32x4{ov[0], ov[1], ov[2], ov[3]};
+  __syncthreads();
+  if (tid < 2 || tid >= 254 || s0 >= L) return;                              // halo threads / positions past the row
+  float res[4];
+  const int half = p.pool_kernel >> 1;
+  if (p.pool_kind == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) res[e] = ov[e];
+  } else {
+    float v[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) v[i] = sc[tid * 4 - 8 + i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float m = -INFINITY, sum = 0.f;
+#pragma unroll
+      for (int j = -8; j <= 8; ++j)
+        if (j >= -half && j <= half) { m = fmaxf(m, v[8 + e + j]); sum += v[8 + e + j]; }   // left-to-right fp32 sum
+      res[e] = p.pool_kind == 2 ? m : sum / (float)p.pool_kernel;            // max_pool1d (:331) / avg_pool1d (:329)
+    }
+  }
+  float* out = reinterpret_cast<float*>(p.scores) + (int64_t)bh * p.scores_stride + s0;
+  *reinterpret_cast<f32x4*>(out) = f32x4{res[0], res[1], res[2], res[3]};     // stride % 4 == 0, s0 % 4 == 0, stride >= roundup(L, 8)
+}
+
+// ------------------------------------------------------------------------------------------------
+// topk_f32_kernel: one workgroup (1024 threads) per row.
+// ------------------------------------------------------------------------------------------------
+constexpr int TKF_MAX = 4096;
+
+__device__ __forceinline__ uint32_t f32_key(float x) {   // ascending unsigned order == ascending float order; -0 == +0
+  if (x == 0.f) x = 0.f;
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// REG: rows of up to 32768 scores keep their keys in registers (32 per thread, loaded once with all loads in flight);
+// longer rows re-read the scores from memory in every pass.
+constexpr int TKF_NV = 32;
+
+template <bool REG>
+__global__ __launch_bounds__(1024) void topk_f32_kernel(TopkParams p) {
+  constexpr int UNR = REG ? TKF_NV : 1;       // full unroll keeps the keys in registers; the streaming form stays a loop
+  __shared__ unsigned long long comp[TKF_MAX];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_digit, sh_kk, sh_cnt, wave_cnt[16], sh_taken;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x, L = p.L;
+  const int k = p.k_per_row ? p.k_per_row[row] : p.k;
+  if (k <= 0) return;
+  const float* sc = reinterpret_cast<const float*>(p.scores) + (int64_t)row * p.scores_stride;
+  uint32_t ureg[REG ? TKF_NV : 1];
+  if constexpr (REG) {
+#pragma unroll
+    for (int j = 0; j < TKF_NV; ++j) {
+      const int i = j * 1024 + tid;
+      ureg[j] = f32_key(sc[i < L ? i : L - 1]);
+    }
+  }
+  const int nv = REG ? TKF_NV : (L + 1023) / 1024;
+  auto key_at = [&](int j, int i) -> uint32_t {
+    if constexpr (REG) return ureg[j];
+    else return i < L ? f32_key(sc[i]) : 0u;
+  };
+  uint32_t prefix = 0, mask = 0, kk = (uint32_t)k;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+#pragma unroll UNR
+    for (int j = 0; j < nv; ++j) {
+      const int i = j * 1024 + tid;
+      const uint32_t u = key_at(j, i);
+      bool act = i < L && (u & mask) == prefix;
+      const uint32_t dg = (u >> shift) & 255u;
+      // scores of one row share their sign and most exponent bits: the top digits put nearly every lane of a wave into
+      // ONE bin, and same-address LDS atomics serialise per lane.  One aggregated round for the first active lane's
+      // digit (one atomic for the whole group), plain atomics for whoever is left.  (More rounds, or none for the lower
+      // digits, measured slower.)
+      const unsigned long long m = __ballot(act);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t dl = (uint32_t)__shfl((int)dg, leader, 64);
+        const unsigned long long same = __ballot(act && dg == dl);
+        if (lane == leader) atomicAdd(&hist[dl], (uint32_t)__popcll(same));
+        act = act && dg != dl;
+      }
+      if (act) atomicAdd(&hist[dg], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {                                   // digits from the top: lane l holds 255-4l .. 252-4l
+      uint32_t c[4], s = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c[j] = hist[255 - (4 * lane + j)]; s += c[j]; }
+      const uint32_t incl = wave_incl_scan_u32(s), excl = incl - s;
+      if (excl < kk && kk <= incl) {
+        uint32_t run = excl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (run < kk && kk <= run + c[j]) { sh_digit = 255 - (4 * lane + j); sh_kk = kk - run; }
+          run += c[j];
+        }
+      }
+    }
+    __syncthreads();
+    prefix |= sh_digit << shift;
+    mask |= 0xffu << shift;
+    kk = sh_kk;
+    __syncthreads();
+  }
+  // prefix = key of the k-th largest score; kk of the scores equal to it are taken, the earliest positions first
+  const uint32_t T = prefix, need = kk;
+  if (tid == 0) { sh_cnt = 0; sh_taken = 0; }
+  __syncthreads();
+#pragma unroll UNR
+  for (int j = 0; j < nv; ++j) {
+    const int i = j * 1024 + tid;
+    const uint32_t u = key_at(j, i);
+    if (i < L && u > T) {
+      const uint32_t pos = atomicAdd(&sh_cnt, 1u);
+      comp[pos] = ((unsigned long long)u << 32) | (0xffffffffu - (uint32_t)i);
+    }
+  }
+  __syncthreads();
+  const uint32_t n_gt = (uint32_t)k - need;            // == sh_cnt
+#pragma unroll UNR
+  for (int j = 0; j < nv; ++j) {                       // the scores equal to the threshold, in position order
+    const uint32_t taken = sh_taken;
+    if (taken >= need) break;
+    const int i = j * 1024 + tid;
+    const bool eq = i < L && key_at(j, i) == T;
+    const unsigned long long bal = __ballot(eq);
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int wv = 0; wv < 16; ++wv) { const uint32_t cw = wave_cnt[wv]; if (wv < wave) before += cw; total += cw; }
+    const uint32_t rank = taken + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (eq && rank < need) comp[n_gt + rank] = ((unsigned long long)T << 32) | (0xffffffffu - (uint32_t)i);
+    __syncthreads();
+    if (tid == 0) sh_taken = taken + total;
+    __syncthreads();
+  }
+  // descending bitonic sort of the k winners: (value desc, index asc); padding 0 is below every real entry
+  int n = 1;
+  while (n < k) n <<= 1;
+  for (int i = k + tid; i < n; i += 1024) comp[i] = 0ull;
+  __syncthreads();
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (n >> 1); t += 1024) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned long long a = comp[lo], b2 = comp[hi];
+        if ((a < b2) == desc) { comp[lo] = b2; comp[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  int32_t* out = p.idx_out + (int64_t)row * p.idx_stride;
+  for (int j = tid; j < k; j += 1024) out[j] = (int32_t)(0xffffffffu - (uint32_t)comp[j]);
+}
+
+hipError_t launch_logits_f32(const LogitsParams& p, hipStream_t st) {
+  dim3 grid(p.nT, p.B * (p.H / p.G));
+  if (p.D == 64) PKV_KLAUNCH(logits_f32_kernel<4>, grid, dim3(256), 0, st, p);
+  else PKV_KLAUNCH(logits_f32_kernel<8>, grid, dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize_f32(const FinalizeParams& p, hipStream_t st) {
+  const int L = p.S - p.w;
+  dim3 grid((L + F32_OUT - 1) / F32_OUT, p.B * p.H);
+  PKV_KLAUNCH(finalize_f32_kernel, grid, dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+int topk_f32_max_k() { return TKF_MAX; }
+
+hipError_t launch_topk_f32(int rows, const TopkParams& p, hipStream_t st) {
+  if (p.L <= TKF_NV * 1024) PKV_KLAUNCH(topk_f32_kernel<true>, dim3(rows), dim3(1024), 0, st, p);
+  else PKV_KLAUNCH(topk_f32_kernel<false>, dim3(rows), dim3(1024), 0, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace pkv

@@ -196,6 +196,11 @@ hipError_t launch_flatten(const FlattenParams& p, hipStream_t st);
 hipError_t launch_merge(int dtype, const MergeParams& p, hipStream_t st);
 hipError_t launch_debug_exp(const float* in, float* out, int64_t n, hipStream_t st);
 hipError_t launch_debug_round(int dtype, const float* in, uint16_t* out, int64_t n, hipStream_t st);
+// fp32 tensors (pkv_f32.hip)
+hipError_t launch_logits_f32(const LogitsParams& p, hipStream_t st);
+hipError_t launch_finalize_f32(const FinalizeParams& p, hipStream_t st);
+hipError_t launch_topk_f32(int rows, const TopkParams& p, hipStream_t st);
+int topk_f32_max_k();
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st);
 hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st);
 

@@ -52,6 +52,24 @@ def test_strerror_and_argument_validation_without_gpu(P):
     assert N.lib.pkv_topk(0, 1, 100000, 5, 16, 100000, None, 16, 5, None) == -5   # L beyond the LDS limit
     assert N.lib.pkv_topk(0, 1, 100, 500, 16, 100, None, 16, 500, None) == -2     # k > L
     assert N.lib.pkv_workspace_bytes(d) > 0
+    # fp32 tensors (PKV_F32 = 2): window policies, D in {64, 128}, topk <= 4096; everything else is PKV_ERR_UNSUPPORTED
+    d.k_stride[2] = 128
+    ws16 = N.lib.pkv_workspace_bytes(d)
+    d.dtype = 2
+    assert N.lib.pkv_workspace_bytes(d) > ws16                  # 4-byte logits and scores
+    assert N.lib.pkv_compress(d, None, 16, 16, 16, 16, None, 16, 1 << 30, None) == -7        # descriptor accepted, null q
+    assert N.lib.pkv_compress_h2o(d, 16, 16, 16, 16, 16, None, 16, 1 << 30, None) == -5
+    d.k_stride[2] = 130                                        # fp32 rows: multiples of 4 elements
+    assert N.lib.pkv_gather_streaming(d, 16, 16, 16, 16, None) == -3
+    d.k_stride[2] = 132
+    assert N.lib.pkv_gather_streaming(d, None, 16, 16, 16, None) == -7
+    d.k_stride[2] = 128
+    d.D = 256
+    assert N.lib.pkv_gather_streaming(d, 16, 16, 16, 16, None) == -5
+    d.D, d.topk = 128, 5000
+    d.S = 8192
+    assert N.lib.pkv_compress(d, 16, 16, 16, 16, 16, None, 16, 1 << 30, None) == -5          # fp32 top-k: k <= 4096
+    assert N.lib.pkv_topk(2, 1, 9000, 4097, 16, 9000, None, 16, 4097, None) == -5
     with pytest.raises(ValueError):
         N.check(-2, "x")
     with pytest.raises(N.PkvError):

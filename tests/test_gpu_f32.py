@@ -1,0 +1,130 @@
+"""fp32 tensors through the HIP path (include/pkv.h PKV_F32: window-score policies, top-k, dense and streaming gather).
+
+The reference is dtype-generic (golden fixture 12 is fp32); with fp32 tensors nothing is rounded between the matmul and
+the top-k, so the only differences to ATen's CPU kernels are fp32 summation orders (the D-long dot product, the softmax
+denominator) and the last ulp of exp().  Bars:
+  * scores: relative difference <= 2e-6 on lattice inputs (the logits are exact there: what is left is exp() and the
+    softmax denominator), <= SCORE_RTOL on Gaussian inputs (the 128-term dot products differ by ~1e-6 absolute);
+  * top-k of given scores: bit-identical to the canonical (value desc, index asc) order, ties and zeros included;
+  * end to end: the selection is the oracle's up to score gaps below SCORE_RTOL (identical on the fixtures used), the
+    compacted K/V are exact copies of the selected rows; StreamingLLM bit-identical.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from inputs import make_qkv, bits
+from oracle import pkv_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SCORE_RTOL = 2e-5
+LATTICE_RTOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyramidkv_amd
+    return pyramidkv_amd
+
+
+@pytest.mark.parametrize("kind", ["gauss", "lattice"])
+@pytest.mark.parametrize("B,H,G,S,D,w,pool,ks,reduce", [
+    (1, 4, 1, 1000, 128, 8, "maxpool", 7, "sum"),
+    (2, 4, 2, 777, 128, 8, "avgpool", 5, "sum"),
+    (1, 8, 4, 2048, 64, 16, "maxpool", 7, "mean"),
+    (1, 2, 1, 130, 128, 32, None, 1, "sum"),
+    (1, 2, 2, 4100, 128, 64, "avgpool", 13, "sum"),
+])
+def test_window_scores_f32(P, kind, B, H, G, S, D, w, pool, ks, reduce):
+    q, k, _ = make_qkv(B, H, S, D, "fp32", kind, 7 + S)
+    kk = k[:, ::G].contiguous()                                   # un-expanded K for G > 1
+    k_exp = kk.repeat_interleave(G, dim=1)
+    ref = O.pool_scores(O.window_scores(q, k_exp, w, reduce), pool, ks)
+    got = P.ops.score_window(q.to(DEV), kk.to(DEV), w, pool, ks, reduce, kv_group=G).cpu()
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    err = ((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+    assert err <= (LATTICE_RTOL if kind == "lattice" else SCORE_RTOL), err
+
+
+def test_window_scores_f32_strided_views(P):
+    """q/k as non-contiguous views (batch and head strides of a larger buffer)."""
+    B, H, S, D, w = 2, 3, 600, 128, 8
+    big = torch.randn(B, S, H + 2, D + 64, generator=torch.Generator().manual_seed(5))
+    q = big[:, :, 1:1 + H, 32:32 + D].permute(0, 2, 1, 3)        # [B,H,S,D], row stride (H+2)*(D+64), 16-byte aligned rows
+    k = torch.randn(B, H, S, D, generator=torch.Generator().manual_seed(6))
+    ref = O.pool_scores(O.window_scores(q.contiguous(), k, w), "maxpool", 7)
+    got = P.ops.score_window(q.to(DEV), k.to(DEV), w, "maxpool", 7).cpu()
+    assert ((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item() <= SCORE_RTOL
+
+
+@pytest.mark.parametrize("L,k", [(5, 5), (64, 1), (1000, 17), (4097, 120), (32760, 2040), (32760, 4096), (70000, 300)])
+def test_topk_f32_bit_identical_with_ties(P, L, k):
+    g = torch.Generator().manual_seed(L + k)
+    rows = 6
+    s = torch.rand(rows, L, generator=g)
+    s[1] = (s[1] * 16).floor() / 16                              # 16 distinct values: massive ties
+    s[2, : L // 2] = 0.0                                         # zeros (softmax underflow) incl. a tie at the threshold
+    s[3] = -s[3]                                                 # negative scores
+    s[4, ::3] = s[4, 0]                                          # one value repeated across the row
+    s[5] = torch.where(torch.rand(L, generator=g) < 0.5, torch.zeros(L), -torch.zeros(L))   # +0 / -0 are equal
+    ref = O.topk_canonical(s, k)
+    got = P.ops.topk(s.to(DEV), k).cpu().long()
+    assert torch.equal(got, ref)
+
+
+def test_topk_f32_rejects_large_k(P):
+    s = torch.rand(2, 9000, device=DEV)
+    with pytest.raises(ValueError):
+        P.ops.topk(s, 4097)
+
+
+@pytest.mark.parametrize("kind", ["gauss", "lattice", "planted"])
+@pytest.mark.parametrize("S,cap", [(300, 40), (4096, 128), (8192, 2048)])
+def test_snapkv_f32_end_to_end(P, kind, S, cap):
+    B, H, w = 1, 4, 8
+    q, k, v = make_qkv(B, H, S, 128, "fp32", kind, 90 + S)
+    cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+    kc, vc = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV), None, 1)
+    _, _, idx = P.ops.compress(q.to(DEV), k.to(DEV), v.to(DEV), w, cap - w, "maxpool", 7, return_indices=True)
+    idx = idx.cpu().long()
+    kr, vr = O.gather_compact(k, v, idx, w)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)            # exact copies of the rows it selected
+    # the selection: the oracle's, up to swaps between scores closer than SCORE_RTOL
+    s = O.pool_scores(O.window_scores(q, k, w), "maxpool", 7)
+    ridx = O.topk_canonical(s, cap - w)
+    va, vb = torch.gather(s, -1, idx), torch.gather(s, -1, ridx)
+    assert ((va - vb).abs() <= SCORE_RTOL * vb.abs()).all()
+    assert (torch.sort(idx, -1).values[..., 1:] != torch.sort(idx, -1).values[..., :-1]).all()
+    if kind == "lattice":                                                      # exact logits -> the identical index sequence
+        assert torch.equal(idx, ridx)
+    if kind == "planted" and S >= 2048:                                        # the well separated heavy hitters come first, in order
+        assert torch.equal(idx[..., :48], ridx[..., :48])
+
+
+def test_pyramidkv_and_streaming_f32(P):
+    B, H, S, w, cap = 2, 4, 3000, 8, 96
+    q, k, v = make_qkv(B, H, S, 128, "fp32", "planted", 11)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    for layer in (0, 15, 31):
+        cl = P.PyramidKVCluster(num_hidden_layers=32, layer_idx=layer, window_size=w, max_capacity_prompt=cap, kernel_size=7,
+                                pooling="maxpool")
+        kc, vc = cl.update_kv(kd, qd, vd, None, 1)
+        kr, vr = O.pyramidkv_update_kv(k, q, v, w, cap, 7, "maxpool", 32, layer, topk_mode="canonical")
+        assert kc.shape == kr.shape and torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), layer
+    kc, vc = P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
+    kr, vr = O.streamingllm_update_kv(k, q, v, w, cap)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+
+
+def test_f32_unsupported_entry_points_fail_loudly(P):
+    q, k, v = (t.to(DEV) for t in make_qkv(1, 2, 512, 128, "fp32", "gauss", 1))
+    with pytest.raises(ValueError):
+        P.H2OKVCluster(window_size=8, max_capacity_prompt=64).update_kv(k, q, v, None, 1)
+    with pytest.raises(ValueError):
+        P.AdaKVCluster(window_size=8, kernel_size=7, pooling="maxpool", max_capacity_prompt=64, floor=0.2, normalize=True).update_kv(k, q, v)
+    with pytest.raises(ValueError):
+        P.SnapKVCluster(window_size=8, max_capacity_prompt=64, merge="pivot").update_kv(k, q, v, None, 1)

@@ -625,7 +625,7 @@ def test_golden_fixtures_through_hip_path(P):
     index = json.load(open(os.path.join(gold, "index.json")))["cases"]
     stats = {}
     for c in index:
-        if c["dtype"] == "fp32" or c.get("merge"):      # merge fixtures: tests/test_gpu_configs.py::test_merge_golden_fixtures_and_clusters
+        if c.get("merge"):      # merge fixtures: tests/test_gpu_configs.py::test_merge_golden_fixtures_and_clusters
             continue
         z = np.load(os.path.join(gold, c["name"] + ".npz"))
         q, k, v = make_qkv(c["B"], c["H"], c["S"], 128, c["dtype"], c["kind"], c["seed"])
