@@ -391,3 +391,19 @@ def test_head_sizes_64_and_256_window_policies(P, D, dt):
         P.ops.merge_compact(k_exp.to(DEV), v_exp.to(DEV), idx[:, :, :10].contiguous(), w)
     with pytest.raises(ValueError):
         P.ops.score_window(torch.zeros(1, 1, 64, 96, dtype=torch.bfloat16, device=DEV), torch.zeros(1, 1, 64, 96, dtype=torch.bfloat16, device=DEV), 8)
+
+
+def test_h2o_strided_views_gqa_batch(P):
+    """H2O scores with token-major Q/K views (row stride = heads * D), un-expanded GQA K and B = 2; S not a multiple of the
+    64-row LDS tile.  The tile loads are raw buffer loads whose extent comes from the strides: this is their test."""
+    from test_gpu_parity import H2O_MISMATCH_FRAC
+    B, H, G, S, w = 2, 4, 2, 1100, 8
+    g = torch.Generator().manual_seed(77)
+    q_tm = torch.randn(B, S, H, 128, generator=g).to(torch.bfloat16)             # [B,S,H,D] as the projection writes it
+    k_tm = torch.randn(B, S, H // G, 128 + 64, generator=g).to(torch.bfloat16)   # padded rows: stride (H/G) * 192
+    q = q_tm.permute(0, 2, 1, 3)
+    k = k_tm[..., 32:160].permute(0, 2, 1, 3)                                    # 64-byte offset into every row
+    want = O.h2o_scores(q.contiguous(), k.contiguous().repeat_interleave(G, dim=1), w)
+    got = P.ops.score_h2o(q.to(DEV), k_tm.to(DEV)[..., 32:160].permute(0, 2, 1, 3), w, kv_group=G).cpu()
+    frac, mx = score_diff(got, want)
+    assert mx <= 1 and frac <= H2O_MISMATCH_FRAC, (frac, mx)
