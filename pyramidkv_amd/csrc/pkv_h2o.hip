@@ -172,8 +172,6 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b + (int64_t)h * p.qs_h;
   const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const int q0 = blockIdx.x * HWG + wave * HR;
-  const float fmin_v = Elem<T>::finfo_min();
-
   u32x4 qf[4][4];
   int qi[4];
 #pragma unroll
@@ -214,8 +212,10 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int s = s0 + lg * 4 + r;
-            if (qi[n] >= L && s >= L && (s - L) > (qi[n] - L))                // corner mask (:545-551)
-              x[r] = Elem<T>::to_f32(Elem<T>::from_f32(x[r] + fmin_v));
+            // corner mask (:545-551): the reference adds finfo.min, whose exp(x - max) is exactly 0 next to any visible
+            // key (every row sees at least one) - so is exp(-inf), and -inf keeps a lane that has seen ONLY masked keys
+            // out of the statistics (its maximum would be -3.4e38 for bf16, and -max * log2e overflows)
+            if (qi[n] >= L && s >= L && (s - L) > (qi[n] - L)) x[r] = -INFINITY;
             if (s >= S) x[r] = -INFINITY;
           }
         }
