@@ -72,6 +72,11 @@ class _WindowPolicy:
 
     def _compress(self, key_states, query_states, value_states, k, num_key_value_groups, h2o=False):
         gu = _unexpanded_group(key_states, query_states)
+        if k == 0 and getattr(self, "merge", None) is None:
+            # a pyramid layer whose budget came out as 0 past tokens (tiny max_capacity_prompt - window_size, :205-215):
+            # the reference's topk(0) selects nothing and the cat (:271-272) returns the observation window alone
+            w = self.window_size
+            return (_repeat_kv(key_states[:, :, -w:, :], gu).contiguous(), _repeat_kv(value_states[:, :, -w:, :], gu).contiguous())
         if getattr(self, "merge", None) is not None:                                 # :336-339: merge_kv instead of the gather
             g = gu if gu > 1 else _kv_group(num_key_value_groups, query_states.shape[1])
             ks, vs = (key_states, value_states) if gu > 1 else (_dedup_view(key_states, g), _dedup_view(value_states, g))

@@ -1,0 +1,151 @@
+"""Boundary sweep: every policy on SMALL prompts around every tiling boundary of the kernels (64 / 128 / 256-key tiles,
+1008-position finalize blocks, window larger than the past, budget == everything, one selected token ...), against the
+oracle.  The large-shape suites prove the BASELINE configurations; this one looks for what they cannot see (it found NaN
+H2O scores for S < w + 12).
+
+Per case: (1) scores within one unit of the last place of the oracle's on at most a few elements, (2) the selected indices
+are the canonical top-k of the kernel's OWN scores - which ties the selection to the scores exactly, whatever one-unit
+noise they carry - and identical to the oracle's when the scores are, (3) the compacted K/V are exact copies of the rows the
+indices name, in order, followed by the window.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from inputs import make_qkv
+from oracle import pkv_oracle as O
+from test_gpu_parity import DEV, score_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyramidkv_amd
+    return pyramidkv_amd
+
+
+SHAPES = [  # (S, w)
+    (9, 8), (10, 1), (17, 16), (33, 32), (65, 64), (66, 8), (72, 64), (100, 32), (127, 8), (128, 8), (129, 8), (130, 64),
+    (255, 16), (256, 8), (257, 8), (300, 64), (511, 8), (513, 32), (1007, 8), (1016, 8), (1017, 8), (1025, 8), (2023, 16),
+]
+
+
+def _caps(S, w):
+    L = S - w
+    ks = sorted({1, 2, min(L, 7), min(L, 17), max(1, L // 2), max(1, L - 1), L})
+    return [k for k in ks if 1 <= k <= L]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("pool,ks", [("maxpool", 7), ("avgpool", 5), (None, 1)])
+def test_window_policies_small_shapes(P, dt, pool, ks):
+    n_cases = mism = elems = 0
+    for (S, w) in SHAPES:
+        G = 2 if S % 2 else 1
+        # lattice inputs: every q.k is exact in fp32 in any order, so the logits carry no accumulation-order noise (on
+        # Gaussian inputs a logit that lands on a rounding boundary moves a LARGE probability of a short row by 2-3 units)
+        q, k, v = make_qkv(2, 4, S, 128, dt, "lattice", 31 * S + w)
+        kk, vv = k[:, ::G].contiguous(), v[:, ::G].contiguous()          # un-expanded K/V for G > 1
+        ke, ve = kk.repeat_interleave(G, dim=1), vv.repeat_interleave(G, dim=1)
+        qd, kd, vd = q.to(DEV), kk.to(DEV), vv.to(DEV)
+        want_s = O.pool_scores(O.window_scores(q, ke, w), pool, ks)
+        got_s = P.ops.score_window(qd, kd, w, pool, ks, kv_group=G).cpu()
+        frac, mx = score_diff(got_s, want_s)
+        assert mx <= 1 and frac <= max(5e-3, 8.0 / got_s.numel()), (S, w, G, frac, mx)     # max pooling repeats a difference 7 times
+        mism += round(frac * got_s.numel())
+        elems += got_s.numel()
+        for kk_sel in _caps(S, w):
+            kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk_sel, pool, ks, kv_group=G, return_indices=True)
+            idx = idx.cpu().long()
+            assert torch.equal(idx, O.topk_canonical(got_s, kk_sel)), (S, w, G, kk_sel)
+            if frac == 0.0:
+                assert torch.equal(idx, O.topk_canonical(want_s, kk_sel))
+            kr, vr = O.gather_compact(ke, ve, idx, w)
+            assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), (S, w, G, kk_sel)
+            n_cases += 1
+    assert n_cases > 100 and mism / elems <= 2e-3
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_pyramidkv_small_prompts_all_layers(P, dt):
+    """PyramidKV's three branches on prompts around the branch thresholds (q_len < cap: pass-through, q_len < (cap - w) * 2:
+    uniform budget, else the pyramid), every layer of a 32- and a 2-layer model."""
+    for (S, w, cap) in ((60, 8, 64), (64, 8, 64), (100, 8, 64), (111, 8, 64), (112, 8, 64), (113, 8, 64), (300, 16, 48), (40, 32, 33)):
+        q, k, v = make_qkv(1, 2, S, 128, dt, "gauss", S + cap)
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        for layers in (32, 2):
+            for layer in range(layers):
+                cl = P.PyramidKVCluster(num_hidden_layers=layers, layer_idx=layer, window_size=w, max_capacity_prompt=cap, kernel_size=5,
+                                        pooling="avgpool")
+                branch, kk_sel = O.pyramid_budget(cap, w, layers, layer, S, 20)
+                assert cl.layer_budget(S) == (branch, kk_sel)
+                kc, vc = cl.update_kv(kd, qd, vd, None, 1)
+                if branch == "passthrough":
+                    assert kc is kd and vc is vd
+                    continue
+                if kk_sel == 0:                                  # topk(0): the window alone (:271-272)
+                    assert torch.equal(kc.cpu(), k[:, :, -w:]) and torch.equal(vc.cpu(), v[:, :, -w:])
+                    continue
+                got_s = P.ops.score_window(qd, kd, w, "avgpool", 5).cpu()
+                idx = O.topk_canonical(got_s, kk_sel)
+                kr, vr = O.gather_compact(k, v, idx, w)
+                assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), (S, w, cap, layers, layer)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_h2o_and_streaming_small_shapes(P, dt):
+    for (S, w) in SHAPES:
+        q, k, v = make_qkv(1, 2, S, 128, dt, "lattice", 17 * S + w)
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        got_s = P.ops.score_h2o(qd, kd, w).cpu()
+        want_s = O.h2o_scores(q, k, w)
+        frac, mx = score_diff(got_s, want_s)
+        assert mx <= 1 and frac <= max(1e-3, 8.0 / got_s.numel()), (S, w, frac, mx)
+        for kk_sel in _caps(S, w):
+            cap = kk_sel + w
+            kc, vc = P.H2OKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
+            idx = O.topk_canonical(got_s, kk_sel)
+            kr, vr = O.gather_compact(k, v, idx, w)
+            assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), (S, w, kk_sel)
+            kc, vc = P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
+            kr, vr = O.streamingllm_update_kv(k, q, v, w, cap)
+            assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), (S, w, kk_sel)
+
+
+def test_adakv_small_shapes(P):
+    """Ada-SnapKV on small prompts: metadata identical to the oracle's evaluated on the kernel's own scores, flat K/V exact."""
+    for (S, w, cap, H) in ((40, 8, 16, 4), (65, 8, 32, 8), (129, 16, 40, 4), (300, 8, 64, 8), (513, 32, 96, 2), (1030, 8, 128, 8)):
+        for floor in (0.0, 0.2, 1.0):
+            q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", S + H)
+            qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+            cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=floor, normalize=True)
+            kf, vf = cl.update_kv(kd, qd, vd)
+            got_s = P.ops.score_window(qd, kd, w, "maxpool", 7, "mean").cpu()
+            _, caps = O.adakv_head_capacity(got_s, cap - w, floor, True)
+            lens = [int(c) + w for c in caps[0]]
+            assert cl.head_lens.cpu().tolist() == lens, (S, w, cap, H, floor)
+            off = 0
+            kfc, vfc = kf.cpu(), vf.cpu()
+            for h in range(H):
+                n = lens[h] - w
+                idx = O.topk_canonical(got_s[0, h][None], n)[0] if n > 0 else torch.zeros(0, dtype=torch.int64)
+                assert torch.equal(kfc[off:off + n], k[0, h, idx]) and torch.equal(vfc[off:off + n], v[0, h, idx]), (S, h, floor)
+                assert torch.equal(kfc[off + n:off + n + w], k[0, h, -w:]) and torch.equal(vfc[off + n:off + n + w], v[0, h, -w:])
+                off += lens[h]
+            assert off == kf.shape[0] == cl.klen_sum
+
+
+def test_merge_small_shapes(P):
+    """LOOK-M pivot merge on small prompts: bit-identical to the oracle's merge of the same indices."""
+    for (S, w, cap, H, G) in ((20, 8, 12, 2, 1), (65, 8, 24, 4, 2), (129, 16, 40, 4, 1), (300, 8, 64, 8, 4), (513, 32, 96, 2, 1)):
+        q, k, v = make_qkv(2, H, S, 128, "bf16", "gauss", 3 * S + H)
+        kk, vv = k[:, ::G].contiguous(), v[:, ::G].contiguous()
+        ke, ve = kk.repeat_interleave(G, dim=1), vv.repeat_interleave(G, dim=1)
+        qd, kd, vd = q.to(DEV), kk.to(DEV), vv.to(DEV)
+        idx = P.ops.select(qd, kd, w, cap - w, "maxpool", 7, kv_group=G)
+        km, vm = P.ops.merge_compact(kd, vd, idx, w, kv_group=G)
+        kr, vr = O.merge_kv(ke, ve, idx.cpu().long(), w, "pivot")
+        assert torch.equal(km.cpu(), kr) and torch.equal(vm.cpu(), vr), (S, w, cap, H, G)
