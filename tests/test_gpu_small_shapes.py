@@ -154,3 +154,31 @@ def test_merge_small_shapes(P):
         km, vm = P.ops.merge_compact(kd, vd, idx, w, kv_group=G)
         kr, vr = O.merge_kv(ke, ve, idx.cpu().long(), w, "pivot")
         assert torch.equal(km.cpu(), kr) and torch.equal(vm.cpu(), vr), (S, w, cap, H, G)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("D", [64, 256])
+def test_window_policies_small_shapes_head_sizes(P, dt, D):
+    """The same sweep for head sizes 64 and 256 (the general K-scan kernel: MFMA k-steps = D / 32)."""
+    n = 0
+    for (S, w) in SHAPES[::2]:
+        G = 2 if S % 2 else 1
+        q, k, v = make_qkv(1, 4, S, D, dt, "lattice", 7 * S + w + D)
+        kk, vv = k[:, ::G].contiguous(), v[:, ::G].contiguous()
+        ke, ve = kk.repeat_interleave(G, dim=1), vv.repeat_interleave(G, dim=1)
+        qd, kd, vd = q.to(DEV), kk.to(DEV), vv.to(DEV)
+        want_s = O.pool_scores(O.window_scores(q, ke, w), "maxpool", 7)
+        got_s = P.ops.score_window(qd, kd, w, "maxpool", 7, kv_group=G).cpu()
+        frac, mx = score_diff(got_s, want_s)
+        assert mx <= 1 and frac <= max(5e-3, 8.0 / got_s.numel()), (S, w, G, D, frac, mx)
+        for kk_sel in _caps(S, w)[::2]:
+            kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk_sel, "maxpool", 7, kv_group=G, return_indices=True)
+            idx = idx.cpu().long()
+            assert torch.equal(idx, O.topk_canonical(got_s, kk_sel)), (S, w, G, D, kk_sel)
+            kr, vr = O.gather_compact(ke, ve, idx, w)
+            assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), (S, w, G, D, kk_sel)
+            n += 1
+        kc, vc = P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=w + 1).update_kv(kd, qd, vd, None, G)
+        kr, vr = O.streamingllm_update_kv(ke, q, ve, w, w + 1)
+        assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), (S, w, G, D)
+    assert n > 20
