@@ -182,3 +182,42 @@ def test_window_policies_small_shapes_head_sizes(P, dt, D):
         kr, vr = O.streamingllm_update_kv(ke, q, ve, w, w + 1)
         assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), (S, w, G, D)
     assert n > 20
+
+
+def test_random_medium_shapes_window_and_h2o(P):
+    """40 seeded random configurations (S 300..6000, windows 1..64, GQA 1/2/4, odd head counts, B 1..3, every pooling and
+    kernel size, both 16-bit dtypes, budgets anywhere in [1, L]): window score + selection + gather and H2O, as above."""
+    rng = np.random.RandomState(20260924)
+    for case in range(40):
+        S = int(rng.randint(300, 6001))
+        w = int(rng.choice([1, 8, 16, 32, 64]))
+        G = int(rng.choice([1, 2, 4]))
+        H = G * int(rng.randint(1, 4))
+        B = int(rng.randint(1, 4))
+        dt = ("bf16", "fp16")[case % 2]
+        pool, ks = [("maxpool", 7), ("avgpool", 5), ("maxpool", 17), ("avgpool", 13), (None, 1), ("maxpool", 3)][int(rng.randint(0, 6))]
+        L = S - w
+        kk_sel = int(rng.randint(1, L + 1)) if case % 4 else int(rng.choice([1, L, min(L, 4096), min(L, 2040)]))
+        q, k, v = make_qkv(B, H, S, 128, dt, "lattice", 100 + case)
+        kk, vv = k[:, ::G].contiguous(), v[:, ::G].contiguous()
+        ke, ve = kk.repeat_interleave(G, dim=1), vv.repeat_interleave(G, dim=1)
+        qd, kd, vd = q.to(DEV), kk.to(DEV), vv.to(DEV)
+        tag = (case, B, H, G, S, w, dt, pool, ks, kk_sel)
+        want_s = O.pool_scores(O.window_scores(q, ke, w), pool, ks)
+        got_s = P.ops.score_window(qd, kd, w, pool, ks, kv_group=G).cpu()
+        frac, mx = score_diff(got_s, want_s)
+        assert mx <= 1 and frac <= 5e-3, tag + (frac, mx)
+        kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk_sel, pool, ks, kv_group=G, return_indices=True)
+        idx = idx.cpu().long()
+        assert torch.equal(idx, O.topk_canonical(got_s, kk_sel)), tag
+        kr, vr = O.gather_compact(ke, ve, idx, w)
+        assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), tag
+        if case % 3 == 0 and S <= 3000:                           # H2O: S x S on the CPU oracle
+            want_h = O.h2o_scores(q, ke, w)
+            got_h = P.ops.score_h2o(qd, kd, w, kv_group=G).cpu()
+            frac, mx = score_diff(got_h, want_h)
+            assert mx <= 1 and frac <= max(1e-3, 8.0 / got_h.numel()), tag + (frac, mx)
+            kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk_sel, None, 1, kv_group=G, h2o=True, return_indices=True)
+            assert torch.equal(idx.cpu().long(), O.topk_canonical(got_h, kk_sel)), tag
+            kr, vr = O.gather_compact(ke, ve, idx.cpu().long(), w)
+            assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), tag
