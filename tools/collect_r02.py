@@ -163,6 +163,8 @@ if acc:
                 lines.append("| %s | " % k + " | ".join("%.4g -> %.4g" % (b4[k][c], h2o[k][c]) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES")) + " |")
         lines.append("")
 hab = os.path.join(G, "h2o_ab.txt")
+if not os.path.exists(hab):
+    hab = os.path.join(ROOT, "gpurun_out", "h2o_ab.txt")       # tools/r02_h2o_ab.sh run on its own
 if os.path.exists(hab):
     shutil.copy(hab, os.path.join(P, "h2o_ab.txt"))
     lines += ["## H2O kernels before / after, same box (tools/r02_h2o_ab.sh; us per launch, S = 32768, H = 32)\n", "```", open(hab).read().strip(), "```", ""]

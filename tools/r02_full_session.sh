@@ -12,6 +12,9 @@ echo "pytest exit $?" >> $O/pytest.txt
 fi
 cp gpurun_out/parity_report.json $O/parity_report.json 2>/dev/null
 ./tools/bw_probe > $O/bw_probe.json 2> $O/bw_probe.err
+# HBM traffic counters first: the bench line attaches them when they belong to the current kernel sources
+(cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_fetch.log 2>&1 ; timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_write.log 2>&1 ; python $R/tools/pmc_summary.py $O $O/pmc_traffic.json > $O/pmc_summary.log 2>&1)
+cp $O/pmc_traffic.json $R/profiles/r02/pmc_traffic.json 2>/dev/null
 # the driver's command
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 echo "bench exit $?" >> $O/bench.err
@@ -32,9 +35,6 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- p
 echo "rocprof exit $?" >> $O/rocprof.log
 python $R/__graft_entry__.py smoke > $O/smoke.log 2>&1
 echo "smoke exit $?" >> $O/smoke.log
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_write.log 2>&1
-python $R/tools/pmc_summary.py $O $O/pmc_traffic.json > $O/pmc_summary.log 2>&1
 # H2O: kernel stats + issue-port counters (two SQ passes)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_h2o -- python $R/tools/h2o_only.py 32768 > $O/prof_h2o.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_h2o_a -- python $R/tools/h2o_only.py 32768 > $O/pmc_h2o_a.log 2>&1
@@ -42,5 +42,6 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_ANY SQ_WAI
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_h2o_c -- python $R/tools/h2o_only.py 32768 > $O/pmc_h2o_c.log 2>&1
 # the H2O kernels of the parent commit d56ac47 (tools/_h2o_base.so, built by hand) against the current ones, same box
 (cd $R && bash tools/r02_h2o_ab.sh) > $O/h2o_ab.log 2>&1
+cp $R/gpurun_out/h2o_ab.txt $O/h2o_ab.txt 2>/dev/null
 cd $R
 tail -4 $O/pytest.txt; head -c 400 $O/bench.json; echo; tail -2 $O/bench.err
