@@ -219,6 +219,17 @@ def main():
                     v_["traffic_source"] = os.path.relpath(pmc_path, ROOT)
             break
 
+    def attach_north_traffic(north):
+        """PMC traffic of the budget-2048 gather (tools/gather_pmc.py under rocprofv3 --pmc), same staleness rule."""
+        for pmc_path in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("kernel_src_sha16") == src_id:
+                for k_, v_ in (north or {}).items():
+                    if v_ and k_ in pmc.get("kernels", {}):
+                        v_["traffic"] = pmc["kernels"][k_].get("hbm_bytes_per_launch")
+                        v_["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+                break
+
     out = {
         "metric": "prefill tokens/s through KV-compress (PyramidKV budget=%d, S=%d, Llama-3-8B shapes)" % (cap, S),
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -256,6 +267,7 @@ def main():
 
     if world == 1 and not a.no_extras:
         out["grid"], north = grid_rows(P, N, dt, dev, S, H, rl, alg_bytes)
+        attach_north_traffic(north)
         out["roofline_kernels"].update(north)
         out["extras"] = gqa_extra(P, dt, dev, S, H, ks, a.steps) or {}
         out["extras"]["two_streams"] = two_stream_extra(P, dt, dev, S, H, ks, a.steps)

@@ -19,12 +19,22 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         short = name.split("pkv::")[1].split("_kernel")[0]
         if short == "logits2":      # the pipelined variant of the logits kernel reports under the same profiler id
             short = "logits"
+        if os.path.basename(os.path.dirname(os.path.dirname(f))).startswith("pmc_gather"):
+            # tools/gather_pmc.py: budget-2048 gather, B = 1 (512 workgroups of 256 threads) and B = 8 (4096)
+            if short != "gather":
+                continue
+            wgs = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
+            short = {512: "gather_cap2048_B1", 4096: "gather_cap2048_B8"}.get(wgs)
+            if short is None:
+                continue
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 1",
        "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), KiB -> bytes", "kernels": {}}
 for kname, ctr in acc.items():
     fetch = ctr.get("FETCH_SIZE", [])
     write = ctr.get("WRITE_SIZE", [])
+    if not fetch and not write:         # directories of other counter passes (SQ_* of the H2O kernels)
+        continue
     fe = sum(fetch) / len(fetch) * 1024 * 2 if fetch else None
     wr = sum(write) / len(write) * 1024 if write else None
     out["kernels"][kname] = {"fetch_bytes_per_launch_corrected": fe, "write_bytes_per_launch": wr,
