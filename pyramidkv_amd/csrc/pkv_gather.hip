@@ -106,14 +106,8 @@ hipError_t launch_gather(const GatherParams& p0, int max_rows, hipStream_t st) {
   // rows per lane: budgets of ~1000+ rows per head stream best with 8 (16 loads in flight per lane: 13.8 us against 14.6 us for
   // 67 MB at B = 1), small budgets are launch-latency-bound and finish earlier with many small workgroups (measured, profiles/)
   int rpt = p.rpt;
+  if (rpt != 2 && rpt != 4 && rpt != 8 && rpt != 16) rpt = max_rows >= 1024 ? 8 : 2;
   const int ch = p.D / 8;
-  if (rpt != 2 && rpt != 4 && rpt != 8 && rpt != 16) {
-    rpt = max_rows >= 1024 ? 8 : 2;
-    // when 8 rows per lane leave at most two workgroups per CU (B = 1, budget 2048: 512), 16 rows per lane (one per CU,
-    // 32 loads in flight per lane) stream better: 10.9-11.9 us against 12.2-12.6 us for 67 MB; with more workgroups
-    // (B = 8) they are worse (100 vs 95 us)
-    if (rpt == 8 && ch == 16 && (int64_t)p.B * p.H * ((max_rows + 127) / 128) <= 512) rpt = 16;
-  }
   if (ch != 16 && rpt == 16) rpt = 8;                       // the 16-row variant exists for 256-byte rows only
   const int rows = (256 / ch) * rpt;
   const int BH = p.B * p.H;

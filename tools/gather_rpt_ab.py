@@ -1,4 +1,7 @@
-"""gather_kernel rows-per-lane (PKV_GATHER_RPT) at budget 2048, B = 1 and 8: hipEvent time of the gather alone."""
+"""gather_kernel rows-per-lane (PKV_GATHER_RPT) at budget 2048, B = 1 and 8: hipEvent time of the gather alone, launched
+back to back on the same K/V.  CAUTION: at B = 1 the 134 MB of K/V stay in the 256 MB Infinity Cache between launches, so
+these numbers flatter the kernel (16 rows per lane looked 10 % faster here and made no difference inside update_kv, where
+the rows come from HBM: bench.py roofline_kernels.gather_cap2048_B1, PKV_GATHER_RPT=8 / 16: 12.8-12.9 / 12.9-13.1 us)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
