@@ -61,6 +61,20 @@ def _unexpanded_group(key_states, query_states) -> int:
     return hq // hk
 
 
+_MAX_COLS = 256      # the K scan carries kv_group * window columns per key row (include/pkv.h: PKV_ERR_UNSUPPORTED beyond)
+
+
+def _fit_group(key_states, value_states, g: int, window: int):
+    """A GQA group of g query heads x `window` rows must fit the K scan's 256 columns per key row.  Wider groups (g = 8
+    next to window 64: Llama-3-70B shapes with the reference's default window) are split: K/V are expanded by g / g2,
+    g2 = the largest divisor of g with g2 * window <= 256, and the kernels run with kv_group = g2."""
+    if g <= 1 or g * window <= _MAX_COLS:
+        return key_states, value_states, g
+    g2 = max(d for d in range(1, g + 1) if g % d == 0 and d * window <= _MAX_COLS)
+    r = g // g2
+    return _repeat_kv(key_states, r), _repeat_kv(value_states, r), g2
+
+
 class _WindowPolicy:
     """Shared body of SnapKV / PyramidKV / H2O: score -> top-k -> gather in one C call."""
 
@@ -77,8 +91,11 @@ class _WindowPolicy:
             # the reference's topk(0) selects nothing and the cat (:271-272) returns the observation window alone
             w = self.window_size
             return (_repeat_kv(key_states[:, :, -w:, :], gu).contiguous(), _repeat_kv(value_states[:, :, -w:, :], gu).contiguous())
+        key_states, value_states, gu = _fit_group(key_states, value_states, gu, self.window_size)
         if getattr(self, "merge", None) is not None:                                 # :336-339: merge_kv instead of the gather
             g = gu if gu > 1 else _kv_group(num_key_value_groups, query_states.shape[1])
+            if g * self.window_size > _MAX_COLS:
+                g = 1
             ks, vs = (key_states, value_states) if gu > 1 else (_dedup_view(key_states, g), _dedup_view(value_states, g))
             idx = ops.select(query_states, ks, self.window_size, k, self.pooling, self.kernel_size,
                              scale_mode=_cfg.scale_mode, kv_group=g, h2o=h2o)
@@ -87,6 +104,8 @@ class _WindowPolicy:
             return ops.compress(query_states, key_states, value_states, self.window_size, k, self.pooling,
                                 self.kernel_size, scale_mode=_cfg.scale_mode, kv_group=gu, h2o=h2o)
         g = _kv_group(num_key_value_groups, query_states.shape[1])
+        if g * self.window_size > _MAX_COLS:
+            g = 1
         return ops.compress(query_states, _dedup_view(key_states, g), _dedup_view(value_states, g),
                             self.window_size, k, self.pooling, self.kernel_size,
                             scale_mode=_cfg.scale_mode, kv_group=g, h2o=h2o)
@@ -396,6 +415,7 @@ class AdaKVCluster(_FlatPolicy):
         if self.base_capacity > L:                                                   # :700
             return self._passthrough(key_states, value_states, num_heads, q_len, head_dim)
         assert bsz == 1                                                              # :724
+        key_states, value_states, _ = _fit_group(key_states, value_states, _unexpanded_group(key_states, query_states), self.window_size)
         # :706 sorts every row completely; what :709-757 consume of that order is bounded: one head can receive at most
         # H*base entries of the global top-(H*base) (:712-717), so the first M = min(L, H*base) entries per head decide the
         # budgets AND hold every index the gather takes (cap_h <= M).  They come from the top-k kernel (no full sort);
@@ -439,6 +459,7 @@ class HeadKVCluster(_FlatPolicy):
         if self.base_capacity > L:                                                   # :834
             return self._passthrough(key_states, value_states, num_heads, q_len, head_dim)
         assert bsz == 1                                                              # :845
+        key_states, value_states, _ = _fit_group(key_states, value_states, _unexpanded_group(key_states, query_states), self.window_size)
         caps = [min(int(self.head_adaptive_capacity[self.layer_idx][h]), L) for h in range(num_heads)]  # :855 slice
         key = (tuple(caps), str(key_states.device))
         if getattr(self, "_cap_key", None) != key:               # the per-layer capacities are constants: upload them once

@@ -221,3 +221,31 @@ def test_random_medium_shapes_window_and_h2o(P):
             assert torch.equal(idx.cpu().long(), O.topk_canonical(got_h, kk_sel)), tag
             kr, vr = O.gather_compact(ke, ve, idx.cpu().long(), w)
             assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), tag
+
+
+def test_wide_gqa_group_is_split(P):
+    """8 query heads per KV head next to the reference's default window of 64 (Llama-3-70B shapes) is 512 columns per key
+    row, more than the K scan carries (256): the host splits the group (K/V expanded x2, kv_group 4) instead of refusing."""
+    B, H, G, S, w, cap = 1, 16, 8, 700, 64, 96
+    q, k, v = make_qkv(B, H, S, 128, "bf16", "lattice", 99)
+    kk, vv = k[:, ::G].contiguous(), v[:, ::G].contiguous()
+    ke, ve = kk.repeat_interleave(G, dim=1), vv.repeat_interleave(G, dim=1)
+    qd, kd, vd = q.to(DEV), kk.to(DEV), vv.to(DEV)
+    got_s = P.ops.score_window(qd, ke.to(DEV), w, "avgpool", 5).cpu()
+    idx = O.topk_canonical(got_s, cap - w)
+    kr, vr = O.gather_compact(ke, ve, idx, w)
+    for cl in (P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=5, pooling="avgpool"),
+               P.PyramidKVCluster(num_hidden_layers=2, layer_idx=0, window_size=w, max_capacity_prompt=cap, kernel_size=5, pooling="avgpool")):
+        kc, vc = cl.update_kv(kd, qd, vd, None, G)
+        if isinstance(cl, P.SnapKVCluster):
+            assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+        else:
+            assert kc.shape[1] == H and kc.shape[2] == cl.layer_budget(S)[1] + w
+    km, vm = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=5, pooling="avgpool", merge="pivot").update_kv(kd, qd, vd, None, G)
+    kmr, vmr = O.merge_kv(ke, ve, idx, w, "pivot")
+    assert torch.equal(km.cpu(), kmr) and torch.equal(vm.cpu(), vmr)
+    ada = P.AdaKVCluster(window_size=w, kernel_size=5, pooling="avgpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+    kf, vf = ada.update_kv(kd, qd, vd)
+    ref = P.AdaKVCluster(window_size=w, kernel_size=5, pooling="avgpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+    kf2, vf2 = ref.update_kv(ke.to(DEV), qd, ve.to(DEV))
+    assert torch.equal(kf, kf2) and torch.equal(vf, vf2) and ada.head_lens.tolist() == ref.head_lens.tolist()
