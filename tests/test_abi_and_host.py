@@ -220,3 +220,18 @@ def test_passthrough_with_unexpanded_kv_returns_repeat_kv(P):
         assert torch.equal(kc, want_k) and torch.equal(vc, want_v)
     with pytest.raises(ValueError):
         P.SnapKVCluster(window_size=8, max_capacity_prompt=64).update_kv(k[:, :3], q, v[:, :3], None, 4)
+
+
+def test_wide_gqa_groups_are_split_on_the_host(P):
+    """kv_group * window must stay within the K scan's 256 columns: 8 query heads per KV head next to window 64 become
+    kv_group 4 over K/V expanded x2, and query head h still reads the KV head it belongs to."""
+    U = P.pyramidkv_utils
+    k = torch.arange(2 * 3 * 5 * 4, dtype=torch.float32).view(2, 3, 5, 4)          # [B, Hk=3, S, D]
+    v = -k
+    for g, w, want_g2 in ((8, 64, 4), (8, 32, 8), (4, 64, 4), (16, 64, 4), (6, 64, 3), (7, 64, 1), (1, 64, 1)):
+        k2, v2, g2 = U._fit_group(k, v, g, w)
+        assert g2 == want_g2 and g2 * w <= 256 or g2 == g, (g, w, g2)
+        r = g // g2
+        assert k2.shape == (2, 3 * r, 5, 4)
+        for h in range(3 * g):                                                      # query head h -> KV head h // g
+            assert torch.equal(k2[:, h // g2], k[:, h // g]) and torch.equal(v2[:, h // g2], v[:, h // g])
