@@ -9,14 +9,11 @@ denominator) and the last ulp of exp().  Bars:
   * end to end: the selection is the oracle's up to score gaps below SCORE_RTOL (identical on the fixtures used), the
     compacted K/V are exact copies of the selected rows; StreamingLLM bit-identical.
 """
-import json
-import os
 
-import numpy as np
 import pytest
 import torch
 
-from inputs import make_qkv, bits
+from inputs import make_qkv
 from oracle import pkv_oracle as O
 
 pytestmark = pytest.mark.gpu

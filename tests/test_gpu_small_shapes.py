@@ -8,7 +8,6 @@ are the canonical top-k of the kernel's OWN scores - which ties the selection to
 noise they carry - and identical to the oracle's when the scores are, (3) the compacted K/V are exact copies of the rows the
 indices name, in order, followed by the window.
 """
-import itertools
 
 import numpy as np
 import pytest
