@@ -235,3 +235,37 @@ def test_wide_gqa_groups_are_split_on_the_host(P):
         assert k2.shape == (2, 3 * r, 5, 4)
         for h in range(3 * g):                                                      # query head h -> KV head h // g
             assert torch.equal(k2[:, h // g2], k[:, h // g]) and torch.equal(v2[:, h // g2], v[:, h // g])
+
+
+def test_abi_argument_fuzz_never_crashes(P):
+    """3000 random descriptors / pointers through the entry points that validate before they launch: every call returns a
+    documented status (or a size), nothing aborts, throws or reads through a null pointer - also without a GPU."""
+    import random
+    N = P._native
+    rnd = random.Random(1)
+    seen = set()
+    for _ in range(3000):
+        d = N.PkvDesc()
+        d.dtype = rnd.choice([0, 1, 2, 3, -1])
+        d.B, d.H, d.S = rnd.choice([0, 1, 2, 8, 70000]), rnd.choice([0, 1, 8, 32, 33]), rnd.choice([1, 2, 9, 64, 4096, 32768, 200000])
+        d.D, d.kv_group = rnd.choice([32, 64, 96, 128, 256, 512]), rnd.choice([0, 1, 2, 3, 4, 8])
+        for arr in (d.q_stride, d.k_stride, d.v_stride):
+            for i in range(3):
+                arr[i] = rnd.choice([0, 4, 8, 128, 130, 4096, 1 << 33])
+        d.window, d.pool_kind, d.pool_kernel = rnd.choice([0, 1, 8, 64, 65, 100000]), rnd.choice([-1, 0, 1, 2, 3]), rnd.choice([0, 1, 2, 7, 17, 19])
+        d.reduce, d.scale_mode, d.topk = rnd.choice([0, 1]), rnd.choice([0, 1]), rnd.choice([0, 1, 5, 4096, 5000, 1 << 30])
+        ptr = rnd.choice([None, 16, 24, 1 << 20])
+        call = rnd.choice([
+            lambda: N.lib.pkv_compress(d, ptr, 16, 16, 16, 16, None, 16, 1 << 30, None),
+            lambda: N.lib.pkv_compress_h2o(d, 16, 16, 16, 16, 16, None, ptr, 1 << 30, None),
+            lambda: N.lib.pkv_gather_streaming(d, ptr, 16, 16, 16, None),
+            lambda: N.lib.pkv_score_window(d, 16, 16, 16, 4096, 16, 1 << 20, None),
+            lambda: N.lib.pkv_select(d, 16, 16, 0, 16, 16, 1 << 20, None),
+            lambda: N.lib.pkv_merge_compact(d, 16, 16, ptr, 8, 16, 16, 16, 1 << 20, None),
+        ])
+        rc = call()
+        assert rc in (0, -1, -2, -3, -4, -5, -6, -7), rc
+        seen.add(rc)
+        assert isinstance(N.lib.pkv_strerror(rc), bytes)
+        assert N.lib.pkv_workspace_bytes(d) >= 0
+    assert {-1, -2, -5} <= seen
