@@ -106,6 +106,18 @@ case(policy="snapkv", dtype="fp16", kind="lattice", B=1, H=4, S=384, w=32, cap=9
 case(policy="h2o", dtype="bf16", kind="gauss", B=1, H=2, S=256, w=8, cap=48, ks=0, pool="none", seed=195, merge="pivot")
 case(policy="streamingllm", dtype="bf16", kind="gauss", B=2, H=2, S=256, w=60, cap=64, ks=0, pool="none", seed=196, merge="pivot")
 
+# Round-2 additions (appended: the numbering above never moves): fp32 tensors through more policies, and tiny prompts where
+# the window is most of the prompt (S < w + 12: where H2O's statistics once produced NaN; a pyramid layer with 0 past tokens)
+case(policy="snapkv", dtype="fp32", kind="lattice", B=2, H=2, S=384, w=32, cap=96, ks=5, pool="avgpool", seed=201)
+case(policy="pyramidkv", dtype="fp32", kind="planted", B=1, H=2, S=2048, w=8, cap=24, ks=1, pool="maxpool", seed=202,
+     layers=32, layer=5, tie_free=True)
+case(policy="streamingllm", dtype="fp32", kind="gauss", B=1, H=2, S=200, w=16, cap=48, ks=0, pool="none", seed=203)
+case(policy="h2o", dtype="bf16", kind="gauss", B=1, H=2, S=20, w=16, cap=18, ks=0, pool="none", seed=204)
+case(policy="h2o", dtype="fp16", kind="gauss", B=1, H=2, S=70, w=64, cap=67, ks=0, pool="none", seed=205)
+case(policy="snapkv", dtype="bf16", kind="gauss", B=1, H=2, S=9, w=8, cap=9, ks=7, pool="maxpool", seed=206)
+case(policy="pyramidkv", dtype="bf16", kind="gauss", B=1, H=2, S=40, w=32, cap=33, ks=5, pool="avgpool", seed=207,
+     layers=2, layer=1)                # the last of two layers gets 0 past tokens: topk(0), the window alone
+
 
 def run_case(c):
     q, k, v = make_qkv(c["B"], c["H"], c["S"], 128, c["dtype"], c["kind"], c["seed"])
