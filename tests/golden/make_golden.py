@@ -117,6 +117,12 @@ case(policy="h2o", dtype="fp16", kind="gauss", B=1, H=2, S=70, w=64, cap=67, ks=
 case(policy="snapkv", dtype="bf16", kind="gauss", B=1, H=2, S=9, w=8, cap=9, ks=7, pool="maxpool", seed=206)
 case(policy="pyramidkv", dtype="bf16", kind="gauss", B=1, H=2, S=40, w=32, cap=33, ks=5, pool="avgpool", seed=207,
      layers=2, layer=1)                # the last of two layers gets 0 past tokens: topk(0), the window alone
+case(policy="adakv", dtype="bf16", kind="gauss", B=1, H=4, S=50, w=8, cap=24, ks=7, pool="maxpool", seed=208,
+     floor=0.2, normalize=True)        # M = min(L, H*base) = L: every head's whole order decides the budgets
+case(policy="adakv", dtype="fp16", kind="gauss", B=1, H=8, S=130, w=64, cap=70, ks=5, pool="avgpool", seed=209,
+     floor=0.0, normalize=True)        # window 64, base capacity 6, no floor
+case(policy="headkv", dtype="bf16", kind="gauss", B=1, H=4, S=60, w=8, cap=24, ks=7, pool="maxpool", seed=210,
+     head_capacity=[[1, 52, 60, 7]], layer=0)   # a capacity above L is cut to L (:855), another is a single token
 
 
 def run_case(c):
