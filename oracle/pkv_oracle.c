@@ -123,6 +123,7 @@ void pkv_o_gather(const uint8_t* src, int64_t row_stride_bytes, int row_bytes, i
 int pkv_o_ada_capacity(const uint16_t* sorted, int dt, int H, int L, int base, double floor_ratio, int normalize,
                        int32_t* cap_out) {
   size_t n = (size_t)H * L;
+  if (base > L) return -2;                                /* :700: the reference does not compress such a prompt */
   kv_t* a = (kv_t*)malloc(sizeof(kv_t) * n);
   if (!a) return -1;
   for (int h = 0; h < H; ++h) {

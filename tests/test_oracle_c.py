@@ -120,3 +120,56 @@ def test_flat_append_vs_torch_oracle(lib):
     lib.pkv_o_update_flatten_view(ptr(bits(cache).copy()), ptr(bits(state).copy()), ptr(lens.numpy().copy()),
                                   ptr(cu.numpy().copy()), H, 256, ptr(out))
     assert np.array_equal(out, bits(want))
+
+
+def test_c_oracle_against_the_real_reference_fixtures(lib):
+    """The C restatement against outputs of the REAL reference directly (tests/golden, not via the torch restatement):
+    on the tie-free fixtures pool -> top-k -> gather reproduce the reference's indices and K/V bit for bit; on the Ada-SnapKV /
+    HeadKV fixtures the head budgets and the var-len metadata are the reference's; the pyramid budgets are the fixtures' k."""
+    import json
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    index = json.load(open(os.path.join(gold, "index.json")))["cases"]
+    checked = {"dense": 0, "flat": 0, "budget": 0}
+    for c in index:
+        if c["dtype"] == "fp32" or c.get("merge"):
+            continue
+        z = np.load(os.path.join(gold, c["name"] + ".npz"))
+        dt = 0 if c["dtype"] == "bf16" else 1
+        q, k, v = make_qkv(c["B"], c["H"], c["S"], 128, c["dtype"], c["kind"], c["seed"])
+        w, S = c["w"], c["S"]
+        if c["policy"] == "pyramidkv" and not bool(z["passthrough"]):
+            br, kk = C.c_int(), C.c_int()
+            lib.pkv_o_pyramid_budget(c["cap"], w, c["layers"], c["layer"], S, 20, C.byref(br), C.byref(kk))
+            assert kk.value == z["idx"].shape[-1], c["name"]
+            checked["budget"] += 1
+        if c["policy"] in ("snapkv", "pyramidkv") and c.get("tie_free"):
+            s = O.window_scores(q, k, w)                                     # fp32 softmax / matmul stay with torch
+            L, kk = S - w, z["idx"].shape[-1]
+            kind = {"maxpool": 2, "avgpool": 1}[c["pool"]]
+            for b in range(c["B"]):
+                for h in range(c["H"]):
+                    pooled = np.zeros(L, dtype=np.uint16)
+                    raw = bits(s[b, h]).copy()                                # keep the array alive across the call
+                    lib.pkv_o_pool(ptr(raw), dt, L, kind, c["ks"], ptr(pooled))
+                    idx = np.zeros(kk, dtype=np.int32)
+                    assert lib.pkv_o_topk(ptr(pooled), dt, L, kk, ptr(idx)) == 0
+                    assert np.array_equal(idx, z["idx"][b, h]), c["name"]
+                    for src, want in ((k, z["kc"]), (v, z["vc"])):
+                        out = np.zeros((kk + w, 128), dtype=np.uint16)
+                        rows = bits(src[b, h]).copy()
+                        lib.pkv_o_gather(ptr(rows), C.c_int64(256), 256, S, w, ptr(idx), kk, ptr(out))
+                        assert np.array_equal(out, want[b, h]), c["name"]
+            checked["dense"] += 1
+        if c["policy"] == "adakv" and c["cap"] - w <= S - w:        # base capacity > L: not compressed (:700)
+            s = O.pool_scores(O.window_scores(q, k, w, "mean"), c["pool"], c["ks"])
+            sv = torch.sort(s, dim=-1, descending=True, stable=True).values
+            H = c["H"]
+            cap = np.zeros(H, dtype=np.int32)
+            svb = bits(sv[0]).copy()
+            assert lib.pkv_o_ada_capacity(ptr(svb), dt, H, s.shape[-1], c["cap"] - w, C.c_double(c["floor"]),
+                                          int(c["normalize"]), ptr(cap)) == 0
+            hl, cu = np.zeros(H, np.int32), np.zeros(H + 1, np.int32)
+            lib.pkv_o_ada_metadata(H, w, ptr(cap), ptr(hl), ptr(cu))
+            assert np.array_equal(hl, z["head_lens"]) and np.array_equal(cu, z["cu_klen"]), c["name"]
+            checked["flat"] += 1
+    assert checked["dense"] >= 4 and checked["flat"] >= 3 and checked["budget"] >= 5, checked
