@@ -36,6 +36,8 @@ for name in ("bench.json", "sweep.json", "bw_probe.json", "parity_report.json", 
              "pytest.txt", "bench_rccl_n1.json", "bench_rccl_n1.log", "bench_rccl_n1_perlayer.json", "bench_n2_gloo.json"):
     if os.path.exists(os.path.join(G, name)):
         shutil.copy(os.path.join(G, name), os.path.join(P, name))
+    elif name == "parity_report.json" and os.path.exists(os.path.join(ROOT, "gpurun_out", name)):
+        shutil.copy(os.path.join(ROOT, "gpurun_out", name), os.path.join(P, name))     # the suite ran in its own gpurun call
 lines = ["# Profiles, round r02\n", "All numbers measured on one MI355X (gfx950) through `gpurun` by `tools/r02_full_session.sh`; raw files sit next to "
          "this summary.  Kernel sources: sha16 `%s`.\n" % src_sha()]
 
