@@ -248,3 +248,60 @@ def test_wide_gqa_group_is_split(P):
     ref = P.AdaKVCluster(window_size=w, kernel_size=5, pooling="avgpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
     kf2, vf2 = ref.update_kv(ke.to(DEV), qd, ve.to(DEV))
     assert torch.equal(kf, kf2) and torch.equal(vf, vf2) and ada.head_lens.tolist() == ref.head_lens.tolist()
+
+
+def test_no_writes_outside_the_caller_buffers(P):
+    """Every output the C ABI writes lives between two canary regions inside one big buffer (outputs sized exactly as
+    include/pkv.h states, odd lengths and budgets): after the call the canaries are intact, i.e. no kernel stores a byte
+    outside [out, out + size) - torch's allocator rounds allocations up and would hide such a store."""
+    N, ops = P._native, P.ops
+    CAN = 4096
+
+    def guarded(nbytes):
+        buf = torch.full((CAN + ((nbytes + 255) // 256) * 256 + CAN,), 0xA5, dtype=torch.uint8, device=DEV)
+        return buf, buf[CAN:CAN + nbytes]
+
+    def intact(buf, nbytes):
+        return bool((buf[:CAN] == 0xA5).all()) and bool((buf[CAN + nbytes:] == 0xA5).all())
+
+    for (dt, es) in ((torch.bfloat16, 2), (torch.float16, 2), (torch.float32, 4)):
+        for (B, H, G, S, w, k_sel, pool, ks) in ((1, 4, 2, 1003, 8, 37, "maxpool", 7), (2, 2, 1, 77, 16, 61, "avgpool", 5), (1, 2, 1, 4099, 64, 1, None, 1),
+                                                (1, 8, 4, 300, 32, 268, "maxpool", 17)):
+            q = torch.randn(B, H, S, 128, device=DEV).to(dt)
+            k = torch.randn(B, H // G, S, 128, device=DEV).to(dt)
+            v = torch.randn(B, H // G, S, 128, device=DEV).to(dt)
+            L = S - w
+            Lp = (L + 7) // 8 * 8
+            with torch.cuda.device(q.device):
+                d = ops.make_desc(q, k, v, w, pool, ks, "sum", "div", k_sel, G)
+                ws = torch.empty(N.lib.pkv_workspace_bytes(d), dtype=torch.uint8, device=DEV)
+                # pkv_compress: k_out, v_out [B,H,k+w,D], idx_out [B,H,k]
+                nb = B * H * (k_sel + w) * 128 * es
+                kb, ko = guarded(nb)
+                vb, vo = guarded(nb)
+                ib, io = guarded(B * H * k_sel * 4)
+                N.check(N.lib.pkv_compress(d, q.data_ptr(), k.data_ptr(), v.data_ptr(), ko.data_ptr(), vo.data_ptr(), io.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_compress")
+                torch.cuda.synchronize()
+                assert intact(kb, nb) and intact(vb, nb) and intact(ib, B * H * k_sel * 4), ("compress", dt, S, w, k_sel)
+                idx = io.view(torch.int32).view(B, H, k_sel)
+                assert int(idx.min()) >= 0 and int(idx.max()) < L
+                # pkv_score_window: [B*H][stride] with stride = Lp: columns [0, L) written, nothing past the last row
+                sb, so = guarded(B * H * Lp * es)
+                N.check(N.lib.pkv_score_window(d, q.data_ptr(), k.data_ptr(), so.data_ptr(), Lp, ws.data_ptr(), ws.numel(), N.stream_ptr()),
+                        "pkv_score_window")
+                torch.cuda.synchronize()
+                assert intact(sb, B * H * Lp * es), ("score_window", dt, S, w)
+                # pkv_topk on those scores: [rows][k]
+                tb, to = guarded(B * H * k_sel * 4)
+                N.check(N.lib.pkv_topk(N.dtype_code(dt), B * H, L, k_sel, so.data_ptr(), Lp, None, to.data_ptr(), k_sel, N.stream_ptr()), "pkv_topk")
+                torch.cuda.synchronize()
+                assert intact(tb, B * H * k_sel * 4), ("topk", dt, S, k_sel)
+                assert torch.equal(to.view(torch.int32).view(B, H, k_sel), idx)
+                if dt != torch.float32:                            # H2O
+                    kb, ko = guarded(nb)
+                    vb, vo = guarded(nb)
+                    N.check(N.lib.pkv_compress_h2o(d, q.data_ptr(), k.data_ptr(), v.data_ptr(), ko.data_ptr(), vo.data_ptr(), None,
+                                                   ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_compress_h2o")
+                    torch.cuda.synchronize()
+                    assert intact(kb, nb) and intact(vb, nb), ("h2o", dt, S, w, k_sel)
