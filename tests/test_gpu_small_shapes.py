@@ -305,3 +305,76 @@ def test_no_writes_outside_the_caller_buffers(P):
                                                    ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_compress_h2o")
                     torch.cuda.synchronize()
                     assert intact(kb, nb) and intact(vb, nb), ("h2o", dt, S, w, k_sel)
+
+
+def test_no_writes_outside_any_buffer_the_host_layer_allocates(P):
+    """The same canary idea for everything pyramidkv_amd.ops allocates (outputs, index lists, metadata, the workspace):
+    torch.empty / empty_like inside ops are routed through guarded allocations for the duration of the test, every policy
+    runs on odd shapes, then all canaries are checked.  Covers the flat (Ada-SnapKV / HeadKV) paths with their bound-sized
+    buffers, the merge, StreamingLLM and the decode-time append."""
+    import types
+    CAN = 4096
+    live = []
+
+    class Proxy(types.ModuleType):
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def _guard(shape, dtype, device):
+            n = 1
+            for s_ in shape:
+                n *= int(s_)
+            nbytes = n * torch.empty(0, dtype=dtype).element_size()
+            buf = torch.full((CAN + ((nbytes + 255) // 256) * 256 + CAN,), 0xA5, dtype=torch.uint8, device=device)
+            live.append((buf, nbytes))
+            return buf[CAN:CAN + nbytes].view(dtype).view(*shape)
+
+        def empty(self, *size, dtype=torch.float32, device=None, pin_memory=False, **kw):
+            if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+                size = tuple(size[0])
+            if device is None or torch.device(device).type != "cuda":
+                return torch.empty(*size, dtype=dtype, device=device, pin_memory=pin_memory, **kw)
+            return self._guard(size, dtype, device)
+
+        def empty_like(self, t, **kw):
+            return self._guard(tuple(t.shape), t.dtype, t.device) if t.is_cuda and not kw else torch.empty_like(t, **kw)
+
+    ops = P.ops
+    saved_torch, saved_ws = ops.torch, dict(ops._WS) if hasattr(ops, "_WS") else None
+    ops.torch = Proxy("torch_proxy")
+    if hasattr(ops, "_WS"):
+        ops._WS.clear()                                            # the workspace is re-allocated (guarded) on first use
+    try:
+        for dt in (torch.bfloat16, torch.float16):
+            for (H, G, S, w, cap) in ((4, 2, 1003, 8, 45), (8, 4, 333, 32, 40), (2, 1, 4099, 16, 531)):
+                q = torch.randn(1, H, S, 128, device=DEV).to(dt)
+                k = torch.randn(1, H // G, S, 128, device=DEV).to(dt)
+                v = torch.randn(1, H // G, S, 128, device=DEV).to(dt)
+                P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool").update_kv(k, q, v, None, G)
+                P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=5, pooling="avgpool", merge="pivot").update_kv(k, q, v, None, G)
+                P.PyramidKVCluster(num_hidden_layers=8, layer_idx=3, window_size=w, max_capacity_prompt=cap, kernel_size=7,
+                                   pooling="maxpool").update_kv(k, q, v, None, G)
+                P.H2OKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(k, q, v, None, G)
+                P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(k, q, v, None, G)
+                for floor in (0.0, 0.2):
+                    P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=floor,
+                                   normalize=True).update_kv(k, q, v)
+                caps = [[(7 * h + 3) % (cap - w) + 1 for h in range(H)]]
+                hk = P.HeadKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, layer_idx=0,
+                                     num_hidden_layers=1, head_capacity=caps)
+                kf, vf = hk.update_kv(k, q, v)
+                state = torch.randn(H, 128, device=DEV).to(dt)
+                ops.update_flatten_view(kf, state, hk.head_lens, hk.cu_klen)
+                sc = ops.score_window(q, k, w, "maxpool", 7, kv_group=G)
+                ops.topk(sc, 17)
+                ops.sort_rows(sc[0])
+        torch.cuda.synchronize()
+        assert len(live) > 100
+        for buf, nbytes in live:
+            assert bool((buf[:CAN] == 0xA5).all()) and bool((buf[CAN + nbytes:] == 0xA5).all()), (nbytes, buf.numel())
+    finally:
+        ops.torch = saved_torch
+        if saved_ws is not None:
+            ops._WS.clear()
+            ops._WS.update(saved_ws)
