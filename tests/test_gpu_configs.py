@@ -435,3 +435,27 @@ def test_h2o_tile_boundaries(P, dt):
             assert mx <= 1 and frac <= max(H2O_MISMATCH_FRAC, 8.0 / got.numel()), (S, w, G, frac, mx)
     _report(f"h2o_tile_boundaries/{dt}", dict(worst_mismatch_frac=worst, pooled_mismatch_frac=bad / total))
     assert bad / total <= H2O_MISMATCH_FRAC, (bad, total)          # measured: bf16 8.8e-5, fp16 7.3e-4
+
+
+def test_one_million_token_prompt(P):
+    """S = 1 048 576 (H = 2, bf16): 64-bit offsets everywhere, the long-row top-k (32 segments), 8192 K-scan stages per head.
+    Scores vs the oracle (O(w S D) on the CPU), selection = canonical top-k of the kernel's scores, K/V exact copies."""
+    B, H, S, w, cap = 1, 2, 1 << 20, 8, 128
+    g = torch.Generator().manual_seed(123)
+    q = torch.randn(B, H, S, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, H, S, 128, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, H, S, 128, generator=g).to(torch.bfloat16)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    want = O.pool_scores(O.window_scores(q, k, w), "maxpool", 7)
+    got = P.ops.score_window(qd, kd, w, "maxpool", 7).cpu()
+    frac, mx = score_diff(got, want)
+    assert mx <= 1 and frac <= SCORE_FRAC, (frac, mx)
+    kc, vc, idx = P.ops.compress(qd, kd, vd, w, cap - w, "maxpool", 7, return_indices=True)
+    idx = idx.cpu().long()
+    assert torch.equal(idx, O.topk_canonical(got, cap - w))
+    kr, vr = O.gather_compact(k, v, idx, w)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+    kc2, vc2 = P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, 1)
+    kr, vr = O.streamingllm_update_kv(k, q, v, w, cap)
+    assert torch.equal(kc2.cpu(), kr) and torch.equal(vc2.cpu(), vr)
+    _report("one_million_tokens", dict(score_mismatch_frac=frac, score_max_ulp=mx))
