@@ -459,3 +459,22 @@ def test_one_million_token_prompt(P):
     kr, vr = O.streamingllm_update_kv(k, q, v, w, cap)
     assert torch.equal(kc2.cpu(), kr) and torch.equal(vc2.cpu(), vr)
     _report("one_million_tokens", dict(score_mismatch_frac=frac, score_max_ulp=mx))
+
+
+def test_batch_64_by_32_heads(P):
+    """2048 (batch, head) rows in one call (B = 64, H = 32, S = 1024, un-expanded GQA 4): grid dimensions and row offsets far
+    from the single-sequence case; selection and K/V vs the oracle on the kernel's scores, scores vs the oracle."""
+    B, H, G, S, w, cap = 64, 32, 4, 1024, 8, 72
+    q, k, v = make_qkv(B, H, S, 128, "bf16", "lattice", 640)
+    kk, vv = k[:, ::G].contiguous(), v[:, ::G].contiguous()
+    ke, ve = kk.repeat_interleave(G, dim=1), vv.repeat_interleave(G, dim=1)
+    qd, kd, vd = q.to(DEV), kk.to(DEV), vv.to(DEV)
+    want = O.pool_scores(O.window_scores(q, ke, w), "avgpool", 5)
+    got = P.ops.score_window(qd, kd, w, "avgpool", 5, kv_group=G).cpu()
+    frac, mx = score_diff(got, want)
+    assert mx <= 1 and frac <= SCORE_FRAC, (frac, mx)
+    kc, vc, idx = P.ops.compress(qd, kd, vd, w, cap - w, "avgpool", 5, kv_group=G, return_indices=True)
+    idx = idx.cpu().long()
+    assert torch.equal(idx, O.topk_canonical(got, cap - w))
+    kr, vr = O.gather_compact(ke, ve, idx, w)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
