@@ -478,3 +478,32 @@ def test_batch_64_by_32_heads(P):
     assert torch.equal(idx, O.topk_canonical(got, cap - w))
     kr, vr = O.gather_compact(ke, ve, idx, w)
     assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+
+
+def test_adakv_and_headkv_long_rows(P):
+    """Ada-SnapKV / HeadKV beyond one top-k workgroup's LDS (L > 57 344: the top-M lists come through the segmented top-k):
+    S = 70 001, 8 query heads over 2 un-expanded KV heads; budgets, metadata and flat K/V vs the oracle's arithmetic on the
+    kernel's own scores."""
+    S, H, G, w, cap = 70001, 8, 4, 8, 136
+    q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 7001)
+    kk, vv = k[:, ::G].contiguous(), v[:, ::G].contiguous()
+    ke, ve = kk.repeat_interleave(G, dim=1), vv.repeat_interleave(G, dim=1)
+    qd, kd, vd = q.to(DEV), kk.to(DEV), vv.to(DEV)
+    got_s = P.ops.score_window(qd, kd, w, "maxpool", 7, "mean", kv_group=G).cpu()
+    sidx, caps = O.adakv_head_capacity(got_s, cap - w, 0.2, True)
+    ada = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+    kf, vf = ada.update_kv(kd, qd, vd)
+    hk_caps = [[100, 1, 300, 7, 64, 128, 90, 11]]
+    hk = P.HeadKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, layer_idx=0, num_hidden_layers=1,
+                         head_capacity=hk_caps)
+    kh, vh = hk.update_kv(kd, qd, vd)
+    for cl, (kx, vx), per_head in ((ada, (kf, vf), [int(c) for c in caps[0]]), (hk, (kh, vh), hk_caps[0])):
+        assert cl.head_lens.cpu().tolist() == [c + w for c in per_head]
+        kx, vx, off = kx.cpu(), vx.cpu(), 0
+        for h in range(H):
+            n = per_head[h]
+            idx = sidx[0, h, :n]
+            assert torch.equal(kx[off:off + n], ke[0, h, idx]) and torch.equal(vx[off:off + n], ve[0, h, idx]), h
+            assert torch.equal(kx[off + n:off + n + w], ke[0, h, -w:]) and torch.equal(vx[off + n:off + n + w], ve[0, h, -w:]), h
+            off += n + w
+        assert off == kx.shape[0] == cl.klen_sum
