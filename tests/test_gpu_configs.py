@@ -507,3 +507,17 @@ def test_adakv_and_headkv_long_rows(P):
             assert torch.equal(kx[off + n:off + n + w], ke[0, h, -w:]) and torch.equal(vx[off + n:off + n + w], ve[0, h, -w:]), h
             off += n + w
         assert off == kx.shape[0] == cl.klen_sum
+
+
+def test_merge_long_odd_prompt(P):
+    """LOOK-M merge on a 40 001-token prompt (several 8192-pivot chunks per kept row, odd tail), un-expanded GQA 2, two
+    batches: bit-identical to the oracle's merge of the same indices."""
+    B, H, G, S, w, cap = 2, 4, 2, 40001, 8, 136
+    q, k, v = make_qkv(B, H, S, 128, "bf16", "gauss", 4001)
+    kk, vv = k[:, ::G].contiguous(), v[:, ::G].contiguous()
+    ke, ve = kk.repeat_interleave(G, dim=1), vv.repeat_interleave(G, dim=1)
+    qd, kd, vd = q.to(DEV), kk.to(DEV), vv.to(DEV)
+    idx = P.ops.select(qd, kd, w, cap - w, "maxpool", 7, kv_group=G)
+    km, vm = P.ops.merge_compact(kd, vd, idx, w, kv_group=G)
+    kr, vr = O.merge_kv(ke, ve, idx.cpu().long(), w, "pivot")
+    assert torch.equal(km.cpu(), kr) and torch.equal(vm.cpu(), vr)
