@@ -17,6 +17,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
   `roofline_kernels`  every kernel of the headline workload AND the north-star kernel at its target configuration:
                       `gather_cap2048_B1` / `gather_cap2048_B8` (SnapKV budget 2048, S = 32768; 67.1 MB x B),
   `grid`              single update_kv calls at B in {1,8} x budget in {128,2048} (device time per kernel),
+  `sweep`             BASELINE.json's synthetic sweep: B in {1,2,4,8} x S in {4k,8k,16k,32k}; per single update_kv call (one
+                      layer): tokens/s = B*S / call time, and the call's algorithmic bytes against the HBM roofline,
   `gpu_eager_baseline` the reference's eager op sequence (oracle restatement) run by PyTorch-ROCm on this same GPU,
   `cpu_baseline`      the same op sequence on this node's host cores.
 """
@@ -271,6 +273,7 @@ def main():
         out["roofline_kernels"].update(north)
         out["extras"] = gqa_extra(P, dt, dev, S, H, ks, a.steps) or {}
         out["extras"]["two_streams"] = two_stream_extra(P, dt, dev, S, H, ks, a.steps)
+        out["sweep"] = seq_batch_sweep(P, dt, dev, H, alg_bytes)
         out["gpu_eager_baseline"] = gpu_eager_baseline(dt, dev, S, H, cap)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sets = make_sets(1, Hl, S, dt, dev, 1234 + rank, 1)
@@ -280,6 +283,37 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def seq_batch_sweep(P, dt, dev, H, alg_bytes):
+    """The synthetic sweep BASELINE.json names ([B = 1..8, H = 32, S = 4k..32k, D = 128]): one SnapKV budget-128 update_kv
+    per point, wall time per call (events around 10 calls on rotating inputs) as tokens/s and as a fraction of the HBM
+    roofline over the call's algorithmic bytes."""
+    rows = []
+    for S in (4096, 8192, 16384, 32768):
+        for B in (1, 2, 4, 8):
+            k_sel = 128 - W
+            nset = max(2, min(4, int(1.6e9 // (3 * B * H * S * 256))))
+            sets = make_sets(B, H, S, dt, dev, 100 + B + S, nset)
+            for it in range(3):
+                q, k, v = sets[it % len(sets)]
+                P.ops.compress(q, k, v, W, k_sel, "maxpool", 7)
+            torch.cuda.synchronize()
+            iters = 10
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for it in range(iters):
+                q, k, v = sets[it % len(sets)]
+                P.ops.compress(q, k, v, W, k_sel, "maxpool", 7)
+            ev1.record()
+            torch.cuda.synchronize()
+            call_us = ev0.elapsed_time(ev1) / iters * 1e3
+            alg = alg_bytes(B, H, S, k_sel)
+            rows.append({"B": B, "S": S, "update_kv_us": round(call_us, 2), "tokens_per_s": round(B * S / call_us * 1e6, 0),
+                         "call_effective_frac_of_8TBps": round(sum(alg.values()) / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
+            del sets
+            torch.cuda.empty_cache()
+    return rows
 
 
 def grid_rows(P, N, dt, dev, S, H, rl, alg_bytes):
