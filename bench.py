@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """bench.py - headline benchmark of the KV-compress hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 from a plain shell: bench.py re-executes itself under torch.distributed.run (N ranks, rank r on GPU r,
+        backend nccl = RCCL); already under torch.distributed.run (RANK in the environment): runs as that rank.
 
 Workload (BASELINE.json metric: "prefill tokens/s + KV-compress ms at S=32k budget=128, Llama-3-8B"):
   PyramidKV, budget 128, window 8, maxpool-7 (the reference runners' knobs, run_longbench.py:221,236-237),
@@ -28,6 +30,8 @@ import hashlib
 import io
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -56,6 +60,7 @@ def parse():
     ap.add_argument("--allgather", default="prefill", choices=["prefill", "layer"],
                     help="multi-GPU exchange of the selected indices: one all-gather per prefill (all 32 layers) or one per layer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed step (layers 0 and 31)")
     ap.add_argument("--no-extras", action="store_true", help="skip grid / gqa / gpu_eager_baseline / strong leg")
     ap.add_argument("--cpu-layers", type=int, default=32, help="layer-calls per CPU-baseline pass (32 = the whole step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work spent on the cpu_baseline sample")
@@ -93,14 +98,44 @@ def make_sets(B, Hl, S, dt, dev, seed, nsets):
     return sets
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) from a plain shell: start the N ranks ourselves - one process per GPU through
+    torch.distributed.run on 127.0.0.1, rank r on device r, process group "nccl" (= RCCL over xGMI).  Rank 0's JSON line
+    passes through on stdout; returns the launcher's exit status.  Fewer visible devices than ranks is an error, never a
+    silent change of backend (PKV_BENCH_BACKEND=gloo is the explicit opt-in that puts every rank on GPU 0 of a 1-GPU box)."""
+    backend = os.environ.get("PKV_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d needs %d visible GPUs for the RCCL process group, found %d "
+                         "(PKV_BENCH_BACKEND=gloo runs all ranks on one device: a code-path smoke run, not a measurement)\n"
+                         % (a.gpus, a.gpus, ndev))
+        return 2
+    if ndev < 1:
+        sys.stderr.write("bench.py: no GPU visible\n")
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run, any world size
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if a.gpus > 1 and not launched:
+        raise SystemExit(self_launch(a))
+    if launched and a.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (torch.distributed.run --nproc-per-node %d)"
+                         % (a.gpus, world, a.gpus))
     import pyramidkv_amd as P
     from pyramidkv_amd import _native as N, dist as pdist
 
@@ -135,10 +170,11 @@ def main():
     def timed_leg(B, steps, warmup, sets):
         xch = pdist.PrefillIndexExchange(ks, B, Hl, dev, force=collective) if (collective and a.allgather == "prefill") else None
 
-        def one_step():
+        def one_step(keep=None):
             # The one exchange step of the path: the selected indices (KBs).  No layer's update_kv depends on another layer's
             # gathered indices, so (default) all 32 layers write into one buffer that is all-gathered ONCE per prefill;
             # "--allgather layer" issues one asynchronous collective per layer instead (at most two in flight).
+            # keep = {layer: None}: the parity leg asks for these layers' (K_c, V_c, local indices) of THIS step function.
             outs, pending = None, []
             for layer in range(NUM_LAYERS):
                 q, k, v = sets[layer % len(sets)]
@@ -146,6 +182,9 @@ def main():
                     kc, vc, idx = P.ops.compress(q, k, v, W, ks[layer], "maxpool", 7, idx_out=xch.slot(layer))
                 else:
                     kc, vc, idx = P.ops.compress(q, k, v, W, ks[layer], "maxpool", 7, return_indices=True)
+                if keep is not None and layer in keep:
+                    keep[layer] = (kc, vc, idx.clone())
+                if xch is None:
                     if collective:
                         pending.append(pdist.allgather_indices_async(idx, force=True))
                         if len(pending) > 2:
@@ -177,6 +216,13 @@ def main():
     el, one_step = timed_leg(B, a.steps, a.warmup, sets)
     ms_per_step = el / a.steps * 1e3
     tokens_per_s = B * S * a.steps / el
+    # ---- parity of the TIMED path: the step function that was just timed, layers 0 and 31, against the CPU oracle ----
+    parity = None
+    if rank == 0 and not a.no_parity:
+        keep = {0: None, NUM_LAYERS - 1: None}
+        one_step(keep)
+        torch.cuda.synchronize()
+        parity = parity_block(keep, sets, ks, cap, a, S)
 
     # ---- per-kernel device time over the same K steps (events on the dispatches, inside libpkv) ----
     N.prof_enable(True)
@@ -219,6 +265,8 @@ def main():
                 if k_ in pmc.get("kernels", {}):
                     v_["traffic"] = pmc["kernels"][k_].get("hbm_bytes_per_launch")
                     v_["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+                    v_["traffic_measured_in_run"] = False      # rocprofv3 --pmc passes of the same workload, same kernel sources
+                    v_["traffic_kernel_src_sha16"] = pmc.get("kernel_src_sha16")
             break
 
     def attach_north_traffic(north):
@@ -230,6 +278,8 @@ def main():
                     if v_ and k_ in pmc.get("kernels", {}):
                         v_["traffic"] = pmc["kernels"][k_].get("hbm_bytes_per_launch")
                         v_["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+                        v_["traffic_measured_in_run"] = False
+                        v_["traffic_kernel_src_sha16"] = pmc.get("kernel_src_sha16")
                 break
 
     out = {
@@ -245,8 +295,12 @@ def main():
                    "collective_backend": (backend if collective else None)},
         "roofline": kernels.get("logits"),
         "roofline_kernels": kernels,
+        "parity": parity,
         "kernel_src_sha16": src_id,
     }
+    if collective:
+        out["config"]["process_group_backend"] = dist.get_backend()
+        out["rccl_nranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else None
     # whole-call effective bandwidth: all algorithmic bytes of a call / its wall time
     out["call_effective"] = {"GBps": round(sum(alg.values()) / (ms_per_step / NUM_LAYERS * 1e-3) / 1e9, 1),
                              "frac_of_8TBps": round(sum(alg.values()) / (ms_per_step / NUM_LAYERS * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -271,7 +325,8 @@ def main():
         out["grid"], north = grid_rows(P, N, dt, dev, S, H, rl, alg_bytes)
         attach_north_traffic(north)
         out["roofline_kernels"].update(north)
-        out["extras"] = gqa_extra(P, dt, dev, S, H, ks, a.steps) or {}
+        out["extras"], gqa_rows = gqa_extra(P, N, rl, dt, dev, S, H, ks, a.steps)
+        out["roofline_kernels"].update(gqa_rows)
         out["extras"]["two_streams"] = two_stream_extra(P, dt, dev, S, H, ks, a.steps)
         out["sweep"] = seq_batch_sweep(P, dt, dev, H, alg_bytes)
         out["gpu_eager_baseline"] = gpu_eager_baseline(dt, dev, S, H, cap)
@@ -283,6 +338,45 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_block(keep, sets, ks, cap, a, S):
+    """The timed step's own outputs for layers 0 and 31 (first sequence, this rank's heads) against the CPU oracle
+    (oracle.pyramidkv_update_kv / snapkv_update_kv == the reference's update_kv, canonical tie order) on the same tensors:
+    fraction of heads whose selected index SET / index SEQUENCE / compacted K and V bits are the oracle's.  Where a
+    sequence differs, `order_within_1ulp` says whether the kernel's order is the oracle's order up to scores one unit in
+    the last place apart (the documented floor: ATen's own CPU softmax sums in a machine-dependent order)."""
+    from oracle import pkv_oracle as O
+    res = {"checker": "oracle/pkv_oracle.py on the host CPU, same tensors as the timed step", "layers": {}}
+    agg = {"heads_identical_set": 1.0, "heads_identical_sequence": 1.0, "kv_bit_identical_heads": 1.0, "order_within_1ulp": True}
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    for layer, got in sorted(keep.items()):
+        q, k, v = (t[:1].cpu() for t in sets[layer % len(sets)])
+        kc, vc, idx = (t[:1].cpu() for t in got)
+        with contextlib.redirect_stdout(io.StringIO()):
+            if a.policy == "pyramidkv":
+                kr, vr, ridx = O.pyramidkv_update_kv(k, q, v, W, cap, 7, "maxpool", NUM_LAYERS, layer, return_indices=True)
+            else:
+                kr, vr, ridx = O.snapkv_update_kv(k, q, v, W, cap, 7, "maxpool", return_indices=True)
+            so = O.pool_scores(O.window_scores(q, k, W), "maxpool", 7)
+        ia = idx.long()
+        seq_h = (ia == ridx).all(-1)[0]
+        set_h = (torch.sort(ia, -1).values == torch.sort(ridx, -1).values).all(-1)[0]
+        kv_h = ((kc == kr).flatten(2).all(-1) & (vc == vr).flatten(2).all(-1))[0]
+        # oracle scores read in the kernel's order must be non-increasing up to one unit in the last place
+        sel = torch.gather(so, -1, ia).view(torch.int16).int()
+        key = torch.where(sel < 0, -(sel & 0x7fff), sel)                       # monotone integer image of the 16-bit floats
+        ulp_ok = bool(((key[..., 1:] - key[..., :-1]).max() <= 1).item()) if key.shape[-1] > 1 else True
+        row = {"k": int(ks[layer]), "heads": int(seq_h.numel()),
+               "heads_identical_set": float(set_h.float().mean()), "heads_identical_sequence": float(seq_h.float().mean()),
+               "kv_bit_identical_heads": float(kv_h.float().mean()), "order_within_1ulp": ulp_ok}
+        res["layers"][str(layer)] = row
+        for f in ("heads_identical_set", "heads_identical_sequence", "kv_bit_identical_heads"):
+            agg[f] = min(agg[f], row[f])
+        agg["order_within_1ulp"] = agg["order_within_1ulp"] and ulp_ok
+    res.update(agg)
+    res["shape"] = "[1,%d,%d,128] %s, layers %s of the timed step" % (sets[0][0].shape[1], S, a.dtype, sorted(keep))
+    return res
 
 
 def seq_batch_sweep(P, dt, dev, H, alg_bytes):
@@ -361,11 +455,11 @@ def grid_rows(P, N, dt, dev, S, H, rl, alg_bytes):
     return rows, north
 
 
-def gqa_extra(P, dt, dev, S, H, ks, steps):
+def gqa_extra(P, N, rl, dt, dev, S, H, ks, steps):
     """Extra (not `value`): the headline workload when K/V are handed over BEFORE repeat_kv (8 KV heads, what the
     transformers adapter does): the kernels read every KV head once per group."""
     if H % 4:
-        return None
+        return {}, {}
     sets = []
     for (q, k, v) in make_sets(1, H, S, dt, dev, 4321, 4):
         sets.append((q, k[:, ::4].contiguous(), v[:, ::4].contiguous()))
@@ -381,9 +475,28 @@ def gqa_extra(P, dt, dev, S, H, ks, steps):
         gstep()
     torch.cuda.synchronize()
     ge = time.perf_counter() - t0
+    # per-kernel device time of the same steps: this is the configuration the transformers adapter runs
+    # (monkeypatch.skip_repeat_kv), so its K scan gets a roofline row of its own (K bytes / 4)
+    N.prof_enable(True)
+    N.prof_read(reset=True)
+    for _ in range(steps):
+        gstep()
+    torch.cuda.synchronize()
+    prof = N.prof_read(reset=True)
+    N.prof_enable(False)
+    k_mean = sum(ks) / NUM_LAYERS
+    rows = {
+        "logits_gqa4": rl(prof, "logits", (H // 4) * S * D * E + H * W * D * E, "logits (K/V un-expanded, kv_group 4: 8 KV heads)"),
+        "finalize_gqa4": rl(prof, "finalize", H * (W * S * E + (S - W) * E), "finalize (kv_group 4)"),
+        "topk_gqa4": rl(prof, "topk", H * ((S - W) * E + k_mean * 4), "topk (kv_group 4)"),
+        "gather_gqa4": rl(prof, "gather", 4 * (k_mean + W) * D * E * H, "gather (kv_group 4: rows read from 8 KV heads)"),
+    }
+    alg_total = sum(r["algorithmic_bytes"] for r in rows.values() if r)
     return {"unexpanded_gqa_tokens_per_s": round(S * steps / ge, 1),
             "unexpanded_gqa_us_per_layer": round(ge / steps / NUM_LAYERS * 1e6, 2),
-            "note": "K/V handed over before repeat_kv (8 KV heads for 32 query heads); not the headline value"}
+            "call_effective_frac_of_8TBps": round(alg_total / (ge / steps / NUM_LAYERS) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "K/V handed over before repeat_kv (8 KV heads for 32 query heads); not the headline value"}, \
+        {k_: v_ for k_, v_ in rows.items() if v_}
 
 
 def two_stream_extra(P, dt, dev, S, H, ks, steps):

@@ -237,7 +237,7 @@ def merge_kv(key_states, value_states, indices: torch.Tensor, window_size: int, 
 
 def merge_kv_explicit(key_states, value_states, indices: torch.Tensor, window_size: int):
     """The arithmetic of ``merge_kv`` spelled out element by element - the specification the HIP kernels implement
-    (checked against the ATen form above in tests/test_oracle_merge.py; small cases only, Python loops):
+    (checked against the ATen form above in tests/test_oracle_golden.py; small cases only, Python loops):
       norm      n = dtype(sqrt(sum x^2))                       (torch.norm, fp32 accumulate, one rounding)
       cosine    sim = dtype(dot(dtype(x / n_x), dtype(t / n_t)))  (fp32 accumulate), pivot = FIRST maximum
       merged    m = dtype(dtype(x + t_pivot) / 2)

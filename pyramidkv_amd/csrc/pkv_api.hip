@@ -381,6 +381,7 @@ const char* pkv_strerror(int s) {
 }
 
 int pkv_last_hip_error(void) { return g_last_hip; }
+void pkv_set_last_hip_error(int e) { g_last_hip = e; }   /* internal: other translation units of libpkv report through it */
 
 
 size_t pkv_workspace_bytes(const pkv_desc* d) {

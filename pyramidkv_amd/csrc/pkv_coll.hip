@@ -98,7 +98,8 @@ int pkv_allgather_indices(void* nccl_comm, const int32_t* idx_local, int32_t* id
     const int64_t total = (int64_t)n * count;
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(regroup_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const int32_t*>(ws), idx_all, n, B, H_local, k);
-    if (hipGetLastError() != hipSuccess) return PKV_ERR_HIP;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pkv_set_last_hip_error((int)e); return PKV_ERR_HIP; }
   }
   return PKV_OK;
 }

@@ -4,6 +4,9 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+// records the hipError_t pkv_last_hip_error() reports for this thread (defined in pkv_api.hip; internal to libpkv)
+extern "C" void pkv_set_last_hip_error(int e);
+
 namespace pkv {
 
 // Per-kernel timing (pkv_prof_*): while a single-kernel profiling scope is open the API layer points g_kev at a pair of

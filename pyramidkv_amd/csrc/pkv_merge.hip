@@ -173,7 +173,10 @@ __global__ __launch_bounds__(256) void merge_pivot_kernel(MergeParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float sv = Elem<T>::to_f32(Elem<T>::from_f32(acc[r]));    // similarity in the model dtype (:150)
-          if (col < nt && sv > bestv[it][r]) { bestv[it][r] = sv; besti[it][r] = col; }   // strict >: first maximum
+          // strict >: first maximum.  A NaN similarity (zero-norm row: 0/0 at :146) ranks above everything and the FIRST
+          // NaN wins, as torch.max propagates it (:151)
+          const float bv = bestv[it][r];
+          if (col < nt && (sv > bv || (sv != sv && bv == bv))) { bestv[it][r] = sv; besti[it][r] = col; }
         }
       }
     }
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(256) void merge_pivot_kernel(MergeParams p) {
       for (int o = 1; o < 16; o <<= 1) {
         const float v2 = __shfl_xor(v, o, 64);
         const int i2 = __shfl_xor(ix, o, 64);
-        if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+        const bool n1 = v != v, n2 = v2 != v2;
+        if ((n2 && !n1) || (!n1 && !n2 && v2 > v) || ((n1 == n2) && (n1 || v2 == v) && i2 < ix)) { v = v2; ix = i2; }
       }
       const int row = row_wg + it * MP_ROWS + wave * 16 + lg * 4 + r;
       if (li == 0 && row < n) p.pivot[(int64_t)bh * p.S + row] = ix;

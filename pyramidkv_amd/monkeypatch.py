@@ -77,12 +77,15 @@ def _track_tokens(cache, layer_idx: int, n_new: int, prefill: bool) -> None:
         import types
         inner = cache.get_seq_length
         cache._pkv_seen_tokens = 0
+        cache._pkv_count_layer = layer_idx      # the first patched layer that runs (layer 0 need not be a patched attention)
 
         def get_seq_length(self, layer_idx=0):
             return 0 if inner(layer_idx) == 0 else self._pkv_seen_tokens
 
         cache.get_seq_length = types.MethodType(get_seq_length, cache)
-    if layer_idx == 0:
+    # one forward visits the layers in ascending order: the counter advances on the lowest patched layer index seen
+    if layer_idx <= cache._pkv_count_layer:
+        cache._pkv_count_layer = layer_idx
         cache._pkv_seen_tokens = n_new if prefill else cache._pkv_seen_tokens + n_new
 
 

@@ -13,7 +13,12 @@ import torch
 from . import _native as N
 
 _WS: Dict[Tuple[int, int], torch.Tensor] = {}
-_WS_RETIRED: list = []      # superseded workspaces stay alive: a HIP graph captured earlier has their address baked in
+# Superseded workspaces stay alive while a HIP graph captured earlier may still have their address baked in.  Growth is
+# geometric (every new buffer is >= 2x the one it supersedes), so per (device, stream) the retired buffers sum to less than
+# the live one; the list itself is bounded: beyond _WS_RETIRED_MAX entries the oldest are released (release_workspaces()
+# drops everything, e.g. between serving sessions once no captured graph is replayed any more).
+_WS_RETIRED: list = []
+_WS_RETIRED_MAX = 64
 
 
 def _require_gpu(*ts):
@@ -41,9 +46,17 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
             _WS_RETIRED.append(ws)
+            del _WS_RETIRED[:-_WS_RETIRED_MAX]
         ws = torch.empty(max(nbytes, 2 * ws.numel() if ws is not None else 0, 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = ws
     return ws
+
+
+def release_workspaces() -> None:
+    """Drop every cached and retired workspace (all devices, all streams).  Only safe when no HIP graph captured around
+    ``update_kv`` will be replayed again: a graph replays with the workspace address it was captured with."""
+    _WS.clear()
+    _WS_RETIRED.clear()
 
 
 def make_desc(q: Optional[torch.Tensor], k: torch.Tensor, v: Optional[torch.Tensor], window: int,
@@ -216,9 +229,9 @@ def merge_compact(k, v, idx: torch.Tensor, window: int, kv_group: int = 1):
         ko = torch.empty(B, H, n + window, D, dtype=k.dtype, device=k.device)
         vo = torch.empty_like(ko)
         nb = N.lib.pkv_merge_workspace_bytes(d)
-        ws = torch.empty(nb, dtype=torch.uint8, device=k.device)
+        ws = workspace(nb, k.device)            # the cached per-(device, stream) scratch: the selection that produced idx is done with it
         N.check(N.lib.pkv_merge_compact(d, k.data_ptr(), v.data_ptr(), idx.data_ptr(), n, ko.data_ptr(), vo.data_ptr(),
-                                        ws.data_ptr(), nb, N.stream_ptr()), "pkv_merge_compact")
+                                        ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_merge_compact")
     return ko, vo
 
 

@@ -16,6 +16,9 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
+import threading
+import time
+
 import torch
 
 from . import ops
@@ -70,6 +73,8 @@ def _fit_group(key_states, value_states, g: int, window: int):
     g2 = the largest divisor of g with g2 * window <= 256, and the kernels run with kv_group = g2."""
     if g <= 1 or g * window <= _MAX_COLS:
         return key_states, value_states, g
+    if window > _MAX_COLS:
+        raise ValueError(f"window_size {window} is beyond the {_MAX_COLS} columns per key row of the K scan")
     g2 = max(d for d in range(1, g + 1) if g % d == 0 and d * window <= _MAX_COLS)
     r = g // g2
     return _repeat_kv(key_states, r), _repeat_kv(value_states, r), g2
@@ -91,6 +96,9 @@ class _WindowPolicy:
             # the reference's topk(0) selects nothing and the cat (:271-272) returns the observation window alone
             w = self.window_size
             return (_repeat_kv(key_states[:, :, -w:, :], gu).contiguous(), _repeat_kv(value_states[:, :, -w:, :], gu).contiguous())
+        if k == 0:
+            raise ValueError("merge='pivot' with a layer budget of 0 past tokens (max_capacity_prompt - window_size too small "
+                             "for this layer count, :205-215) is not supported: there is no selected row to merge into")
         key_states, value_states, gu = _fit_group(key_states, value_states, gu, self.window_size)
         if getattr(self, "merge", None) is not None:                                 # :336-339: merge_kv instead of the gather
             g = gu if gu > 1 else _kv_group(num_key_value_groups, query_states.shape[1])
@@ -258,17 +266,18 @@ class StreamingLLMKVCluster:
         return _repeat_kv(kc, g), _repeat_kv(vc, g)       # every head of a group keeps the same tokens
 
 
-_PINNED = {}
+_PINNED = threading.local()      # per host thread: two threads reading capacities back never share a staging buffer
 
 
 def _read_back(t: torch.Tensor):
     """Small device int32 vector -> Python list through a cached pinned buffer (the one host sync of Ada-SnapKV, as the
     reference's ``.item()`` at :718): an asynchronous copy + a stream synchronise instead of a pageable blocking copy."""
     n = t.numel()
-    buf = _PINNED.get(n)
+    cache = _PINNED.__dict__.setdefault("bufs", {})
+    buf = cache.get(n)
     if buf is None:
         buf = torch.empty(n, dtype=t.dtype, pin_memory=True)
-        _PINNED[n] = buf
+        cache[n] = buf
     buf.copy_(t, non_blocking=True)
     torch.cuda.current_stream(t.device).synchronize()
     return buf.tolist()
@@ -276,40 +285,36 @@ def _read_back(t: torch.Tensor):
 
 class _HostMirror:
     """Pinned host int32 [H+1] the budget kernel writes the capacities (and then a sequence number) into: the host polls
-    the last word instead of enqueueing a copy and synchronising the stream (~35 us of the ~130 us call at S = 32k)."""
-    _cache = {}
+    the last word instead of enqueueing a copy and synchronising the stream (~35 us of the ~130 us call at S = 32k).
+
+    One mirror per CLUSTER INSTANCE (the reference builds one Ada-SnapKV cluster per attention layer, :1049): a
+    process-wide buffer keyed by (H, device) would let two threads / streams running Ada-SnapKV on the same device
+    overwrite each other's capacities between the poll and the read.  A cluster instance itself is single-caller state
+    (``head_lens``, ``cu_klen`` ... are attributes the decode step mutates), so nothing is shared beyond it."""
 
     def __init__(self, H):
         self.t = torch.zeros(H + 1, dtype=torch.int32, pin_memory=True)
         self.np = self.t.numpy()                 # shares the pinned memory
         self.H, self.seq = H, 0
 
-    @classmethod
-    def get(cls, H, device):
-        key = (H, str(device))
-        m = cls._cache.get(key)
-        if m is None:
-            m = cls(H)
-            cls._cache[key] = m
-        return m
-
     def next_seq(self):
         self.seq = self.seq % 0x3fffffff + 1
         return self.seq
 
     def wait(self, device):
-        import time
         a, H, seq = self.np, self.H, self.seq
         t_end = time.perf_counter() + 0.5
         spins = 0
         while a[H] != seq:
             spins += 1
-            if spins & 1023 == 0 and time.perf_counter() > t_end:      # a lost signal must not hang the host: fall back
-                torch.cuda.current_stream(device).synchronize()
-                if a[H] != seq:
-                    raise RuntimeError("pyramidkv_amd: the budget kernel did not report its head capacities")
-                break
-        return a[:H].tolist()
+            if spins & 63 == 0:
+                time.sleep(0)                    # hand the GIL to other host threads while the kernel runs
+                if time.perf_counter() > t_end:  # a lost signal must not hang the host: fall back
+                    torch.cuda.current_stream(device).synchronize()
+                    if a[H] != seq:
+                        raise RuntimeError("pyramidkv_amd: the budget kernel did not report its head capacities")
+                    break
+        return a[:H].tolist()                    # copied out before the next call of this instance can reuse the buffer
 
 
 _ADA_TOPM_MAX = 4096      # longest per-head list taken from the top-k kernel; beyond it the rows are sorted completely
@@ -424,7 +429,11 @@ class AdaKVCluster(_FlatPolicy):
         if M <= _ADA_TOPM_MAX:
             if self.pooling not in ('avgpool', 'maxpool'):
                 raise ValueError('Pooling method not supported')
-            mirror = _HostMirror.get(num_heads, key_states.device) if _cfg.host_poll else None
+            mirror = None
+            if _cfg.host_poll:
+                mirror = getattr(self, "_mirror", None)
+                if mirror is None or mirror.H != num_heads:
+                    mirror = self._mirror = _HostMirror(num_heads)
             sorted_idx, cap, head_lens, cu, cuh = ops.ada_select(
                 query_states, key_states, self.window_size, self.pooling, self.kernel_size, M, self.base_capacity,
                 self.floor_ratio, bool(self.normalize), scale_mode=_cfg.scale_mode,

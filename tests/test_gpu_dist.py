@@ -92,6 +92,68 @@ def _ada_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _config4_worker(rank, world, port, q, k, v, ks, oracle_idx, ret):
+    """BASELINE config 4 on ONE device: rank r owns heads [4r, 4r+4) of one 32k sequence, all 32 PyramidKV budget-128
+    layer budgets go through PrefillIndexExchange (one all-gather per prefill)."""
+    _init(rank, world, port)
+    import pyramidkv_amd as P
+    from pyramidkv_amd import dist as pdist
+    H, w = q.shape[1], 8
+    h0, h1 = pdist.shard_heads(H, rank, world)
+    qd, kd, vd = (t[:, h0:h1].contiguous().to(DEV) for t in (q, k, v))
+    xch = pdist.PrefillIndexExchange(ks, 1, h1 - h0, torch.device(DEV, 0))
+    outs = []
+    for layer, kk in enumerate(ks):
+        kc, vc, _ = P.ops.compress(qd, kd, vd, w, kk, "maxpool", 7, idx_out=xch.slot(layer))
+        outs.append((kc, vc))
+    gathered = xch.views(xch.gather_async())
+    ok = len(gathered) == len(ks)
+    bad = []
+    for layer, kk in enumerate(ks):
+        g = gathered[layer]
+        ok_l = g.shape == (1, H, kk) and torch.equal(g.cpu().long(), oracle_idx[layer])        # every rank holds ALL heads' indices == the oracle's
+        if ok_l:                                                                                 # this rank's compacted K/V == the oracle's gather of its heads
+            gi = oracle_idx[layer][:, h0:h1]
+            kr, vr = O.gather_compact(k[:, h0:h1], v[:, h0:h1], gi, w)
+            ok_l = torch.equal(outs[layer][0].cpu(), kr) and torch.equal(outs[layer][1].cpu(), vr)
+        if not ok_l:
+            bad.append(layer)
+    if rank == 0:      # the unsharded HIP path on the whole [1, 32, S, 128] tensors
+        qf, kf, vf = q.to(DEV), k.to(DEV), v.to(DEV)
+        for layer in (0, 13, 31):
+            _, _, iu = P.ops.compress(qf, kf, vf, w, ks[layer], "maxpool", 7, return_indices=True)
+            if not torch.equal(iu, gathered[layer]):
+                bad.append(("unsharded", layer))
+    ret[rank] = (bool(ok and not bad), bad)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_world8_one_gpu():
+    """BASELINE config 4 exactly as north_star partitions it - PyramidKV budget 128, S = 32768, 32 heads sharded 4 per rank
+    over EIGHT ranks, one exchange of the selected indices per prefill - with the eight ranks on this box's one GPU (gloo
+    carries the collective; RCCL refuses two ranks per device): gathered indices == unsharded HIP == oracle for all 32 layer
+    budgets, every rank's compacted K/V == the oracle's gather of its heads."""
+    import pyramidkv_amd as P
+    world, H, S, w, cap = 8, 32, 32768, 8, 128
+    q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 4400)
+    ks = []
+    for layer in range(32):
+        branch, kk = O.pyramid_budget(cap, w, 32, layer, S)
+        assert branch == "pyramid"
+        ks.append(kk)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    s = O.pool_scores(O.window_scores(q, k, w), "maxpool", 7)
+    order = O.topk_canonical(s, max(ks))                       # (value desc, index asc): a prefix is the top-k of every smaller k
+    oracle_idx = [order[..., :kk].contiguous() for kk in ks]
+    for t in (q, k, v):
+        t.share_memory_()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_config4_worker, args=(world, _free_port(), q, k, v, ks, oracle_idx, ret), nprocs=world, join=True)
+    assert all(ret.get(r, (False,))[0] for r in range(world)), dict(ret)
+
+
 @pytest.mark.parametrize("worker", [_snap_worker, _ada_worker], ids=["snapkv", "adakv"])
 def test_head_sharded_world2_hip_path(worker):
     world = 2

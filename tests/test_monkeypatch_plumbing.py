@@ -310,16 +310,26 @@ def test_sliding_window_model_keeps_the_compacted_rows(patched):
         assert lay.keys.shape[2] == cap + new - 1          # nothing cropped (the stock sliding layer would hold 63 rows)
 
 
-def test_positions_follow_the_true_length_without_explicit_positions(patched):
+@pytest.mark.parametrize("family", ["llama", "mistral_sliding"])
+def test_positions_follow_the_true_length_without_explicit_positions(patched, family):
     """After compaction the stock cache reports the compressed length; a decode loop that does not pass position_ids /
     cache_position would rotate the next token as position `cap` instead of S.  The adapter tracks the true token count
     (reference: self.kv_seq_len, llama_model.py:139-145,166,170,172): decoding with and without explicit positions gives
-    the same logits."""
+    the same logits - also on a Mistral config with ``sliding_window`` set (transformers 5 builds sliding cache layers and
+    sliding masks there; round-2 advisor finding)."""
     from transformers import DynamicCache
-    model = _tiny("llama")
     S, cap, w = 150, 48, 8
     ids = torch.randint(0, 97, (1, S), generator=torch.Generator().manual_seed(2))
-    patched.replace_llama("snapkv")
+    if family == "llama":
+        model = _tiny("llama")
+        patched.replace_llama("snapkv")
+    else:
+        from transformers import MistralConfig, MistralForCausalLM
+        torch.manual_seed(0)
+        model = MistralForCausalLM(MistralConfig(
+            vocab_size=97, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+            num_key_value_heads=1, head_dim=128, max_position_embeddings=4096, sliding_window=64)).eval()
+        patched.replace_mistral("snapkv")
     for layer in model.model.layers:
         c = layer.self_attn.config
         c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = w, cap, 7, "maxpool", None

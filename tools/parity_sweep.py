@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Identical-set / identical-sequence rates of the HIP path against the CPU oracle over the whole BASELINE sweep:
+[B in {1,2,4,8}] x [S in {4k,8k,16k,32k}] x budgets {128, 2048} x {bf16, fp16}, H = 32, D = 128, SnapKV knobs of the runners
+(window 8, maxpool-7).  One table (round-2 review item 2c), written to gpurun_out/parity_sweep.json.
+
+Per point: heads whose selected index SET equals the oracle's, heads whose index SEQUENCE equals it, heads whose compacted
+K and V bits equal the oracle's, and whether every differing sequence is the oracle's order up to scores one unit in the
+last place apart.  The oracle sorts once per point (stable, value descending): its prefix is the canonical top-k of both
+budgets.  Test infrastructure: the oracle is the checker here, never the thing measured.
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import pkv_oracle as O   # noqa: E402
+import pyramidkv_amd as P            # noqa: E402
+
+W, D, H = 8, 128, 32
+DEV = torch.device("cuda", 0)
+
+
+def mono16(t):
+    b = t.view(torch.int16).int()
+    return torch.where(b < 0, -(b & 0x7FFF), b)
+
+
+def point(B, S, dt, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    q, k, v = (torch.randn(B, H, S, D, generator=g, device=DEV, dtype=torch.float32).to(dt) for _ in range(3))
+    qc, kc_, vc_ = q.cpu(), k.cpu(), v.cpu()
+    s = O.pool_scores(O.window_scores(qc, kc_, W), "maxpool", 7)
+    order = O.topk_canonical(s, min(2048 - W, S - W))
+    rows = []
+    for cap in (128, 2048):
+        kk = cap - W
+        if kk > S - W:
+            continue
+        kc, vc, idx = P.ops.compress(q, k, v, W, kk, "maxpool", 7, return_indices=True)
+        ridx = order[..., :kk]
+        ia = idx.cpu().long()
+        seq = (ia == ridx).all(-1)
+        st = (torch.sort(ia, -1).values == torch.sort(ridx, -1).values).all(-1)
+        kr, vr = O.gather_compact(kc_, vc_, ridx, W)
+        kv = (kc.cpu() == kr).flatten(2).all(-1) & (vc.cpu() == vr).flatten(2).all(-1)
+        key = mono16(torch.gather(s, -1, ia))
+        ulp_ok = bool(((key[..., 1:] - key[..., :-1]).max() <= 1).item())
+        n = seq.numel()
+        rows.append({"B": B, "S": S, "dtype": str(dt).replace("torch.", ""), "budget": cap, "heads": n,
+                     "heads_identical_set": int(st.sum()), "heads_identical_sequence": int(seq.sum()),
+                     "kv_bit_identical_heads": int(kv.sum()), "order_within_1ulp": ulp_ok,
+                     "set_rate": round(float(st.float().mean()), 6), "sequence_rate": round(float(seq.float().mean()), 6)})
+    return rows
+
+
+def main():
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    out = {"workload": "SnapKV window 8 maxpool-7, H=32, D=128, N(0,1) inputs; HIP path vs oracle (canonical tie order)", "rows": []}
+    t0 = time.time()
+    budget_s = float(os.environ.get("PKV_PARITY_SWEEP_SECONDS", "420"))
+    for dt in (torch.bfloat16, torch.float16):
+        for S in (4096, 8192, 16384, 32768):
+            for B in (1, 2, 4, 8):
+                if time.time() - t0 > budget_s:
+                    out["truncated_at"] = {"dtype": str(dt), "S": S, "B": B}
+                    break
+                out["rows"] += point(B, S, dt, 9000 + B * 131 + S)
+                torch.cuda.empty_cache()
+    rows = out["rows"]
+    tot = sum(r["heads"] for r in rows)
+    out["summary"] = {
+        "points": len(rows), "heads": tot,
+        "set_rate": sum(r["heads_identical_set"] for r in rows) / max(tot, 1),
+        "sequence_rate": sum(r["heads_identical_sequence"] for r in rows) / max(tot, 1),
+        "kv_bit_identical_rate": sum(r["kv_bit_identical_heads"] for r in rows) / max(tot, 1),
+        "all_orders_within_1ulp": all(r["order_within_1ulp"] for r in rows),
+        "by_budget": {str(c): {"heads": sum(r["heads"] for r in rows if r["budget"] == c),
+                               "sequence_rate": sum(r["heads_identical_sequence"] for r in rows if r["budget"] == c)
+                               / max(1, sum(r["heads"] for r in rows if r["budget"] == c))} for c in (128, 2048)},
+        "seconds": round(time.time() - t0, 1)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_sweep.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out["summary"]))
+
+
+if __name__ == "__main__":
+    main()
