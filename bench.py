@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed step (layers 0 and 31)")
     ap.add_argument("--no-extras", action="store_true", help="skip grid / gqa / gpu_eager_baseline / strong leg")
+    ap.add_argument("--only-gqa-extra", action="store_true", help="of the extras run only the un-expanded-GQA leg (A/B sessions)")
     ap.add_argument("--cpu-layers", type=int, default=32, help="layer-calls per CPU-baseline pass (32 = the whole step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work spent on the cpu_baseline sample")
     return ap.parse_args()
@@ -252,9 +253,26 @@ def main():
             "gather": 4 * (k_mean + W) * D * E * n,                      # 2 tensors x (k+w) rows x D x e x (read+write)
         }
 
+    def kernel_rows(prof_, alg_):
+        """One roofline row per kernel that ran.  Small budgets run selection and gather-compaction as ONE launch
+        (topk_gather_kernel): no gather dispatch exists then and the row `topk_gather` carries both kernels' bytes."""
+        rows_ = {}
+        fused = prof_["gather"][1] == 0 and prof_["topk"][1] > 0
+        for name, by in alg_.items():
+            if fused and name == "gather":
+                continue
+            if fused and name == "topk":
+                r = rl(prof_, "topk", by + alg_["gather"], "topk + gather (one launch)")
+                if r:
+                    rows_["topk_gather"] = r
+                continue
+            r = rl(prof_, name, by)
+            if r:
+                rows_[name] = r
+        return rows_
+
     alg = alg_bytes(B, Hl, S, sum(ks) / NUM_LAYERS)
-    kernels = {k_: rl(prof, k_, v_) for k_, v_ in alg.items()}
-    kernels = {k_: v_ for k_, v_ in kernels.items() if v_}
+    kernels = kernel_rows(prof, alg)
     # HBM traffic per launch from rocprofv3 PMC passes (tools/pmc_summary.py).  Only attached when the profile was taken
     # from exactly these kernel sources and this workload; otherwise the field stays null instead of going stale.
     src_id = kernel_src_sha16()
@@ -321,8 +339,11 @@ def main():
         del ssets
         torch.cuda.empty_cache()
 
-    if world == 1 and not a.no_extras:
-        out["grid"], north = grid_rows(P, N, dt, dev, S, H, rl, alg_bytes)
+    if world == 1 and a.only_gqa_extra:
+        out["extras"], gqa_rows = gqa_extra(P, N, rl, dt, dev, S, H, ks, a.steps)
+        out["roofline_kernels"].update(gqa_rows)
+    elif world == 1 and not a.no_extras:
+        out["grid"], north = grid_rows(P, N, dt, dev, S, H, rl, alg_bytes, kernel_rows)
         attach_north_traffic(north)
         out["roofline_kernels"].update(north)
         out["extras"], gqa_rows = gqa_extra(P, N, rl, dt, dev, S, H, ks, a.steps)
@@ -410,7 +431,7 @@ def seq_batch_sweep(P, dt, dev, H, alg_bytes):
     return rows
 
 
-def grid_rows(P, N, dt, dev, S, H, rl, alg_bytes):
+def grid_rows(P, N, dt, dev, S, H, rl, alg_bytes, kernel_rows):
     """Single SnapKV update_kv calls at B in {1,8} x budget in {128,2048}: wall time per call (events around 10 calls) and
     device time per kernel (events on the dispatches).  Returns (rows, {gather_cap2048_B1, gather_cap2048_B8})."""
     rows, north = [], {}
@@ -443,10 +464,9 @@ def grid_rows(P, N, dt, dev, S, H, rl, alg_bytes):
             row = {"policy": "snapkv", "B": B, "budget": cap, "S": S, "update_kv_us": round(call_us, 2),
                    "tokens_per_s": round(B * S / call_us * 1e6, 0),
                    "call_effective_frac_of_8TBps": round(sum(alg.values()) / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-            for name, by in alg.items():
-                r = rl(prof, name, by)
-                if r:
-                    row[name] = {"us": r["avg_us"], "GBps": r["achieved"], "frac": r["frac"], "alg_MB": round(by / 1e6, 2)}
+            for name, r in kernel_rows(prof, alg).items():
+                row[name] = {"us": r["avg_us"], "GBps": r["achieved"], "frac": r["frac"],
+                             "alg_MB": round(r["algorithmic_bytes"] / 1e6, 2)}
             rows.append(row)
             if cap == 2048:
                 north["gather_cap2048_B%d" % B] = rl(prof, "gather", alg["gather"], "gather (SnapKV budget 2048, S=%d, B=%d)" % (S, B))
@@ -485,11 +505,14 @@ def gqa_extra(P, N, rl, dt, dev, S, H, ks, steps):
     prof = N.prof_read(reset=True)
     N.prof_enable(False)
     k_mean = sum(ks) / NUM_LAYERS
+    tk_b, ga_b = H * ((S - W) * E + k_mean * 4), 4 * (k_mean + W) * D * E * H
+    fused = prof["gather"][1] == 0
     rows = {
         "logits_gqa4": rl(prof, "logits", (H // 4) * S * D * E + H * W * D * E, "logits (K/V un-expanded, kv_group 4: 8 KV heads)"),
         "finalize_gqa4": rl(prof, "finalize", H * (W * S * E + (S - W) * E), "finalize (kv_group 4)"),
-        "topk_gqa4": rl(prof, "topk", H * ((S - W) * E + k_mean * 4), "topk (kv_group 4)"),
-        "gather_gqa4": rl(prof, "gather", 4 * (k_mean + W) * D * E * H, "gather (kv_group 4: rows read from 8 KV heads)"),
+        "topk_gather_gqa4" if fused else "topk_gqa4":
+            rl(prof, "topk", tk_b + (ga_b if fused else 0), "topk + gather (one launch, kv_group 4)" if fused else "topk (kv_group 4)"),
+        "gather_gqa4": rl(prof, "gather", ga_b, "gather (kv_group 4: rows read from 8 KV heads)"),
     }
     alg_total = sum(r["algorithmic_bytes"] for r in rows.values() if r)
     return {"unexpanded_gqa_tokens_per_s": round(S * steps / ge, 1),

@@ -50,6 +50,9 @@ struct LogitsParams {
   int nt;            // nontemporal K loads
   int nst;           // logits2_kernel: 128-key stages per workgroup (nT = chunks per head)
   int ablate;        // 0 = full kernel; 1..3 = measurement-only ablations (PKV_LOGITS_ABLATE)
+  int fexp;          // logits2_kernel: hardware exp2 for the partial (max, sum exp) statistics
+  int st_mode;       // logits2_kernel: logits stores 0 = plain, 1 = nontemporal, 2 = write-through (sc1)
+  uint32_t logits_bytes;   // extent of the logits buffer (raw-buffer stores)
   int64_t qs_b, qs_h, qs_s;
   int64_t ks_b, ks_h, ks_s;
   int scale_mode;
@@ -63,6 +66,7 @@ struct FinalizeParams {
   int64_t scores_stride;
   int B, H, S, w, Sp, nT;
   int pool_kind, pool_kernel, reduce;
+  int pre;               // issue the logits-row loads before the statistics are reduced (w <= 8)
   void* cmax;            // [B*H][cmax_stride] max pooled score of every 8-position chunk (may be null)
   int64_t cmax_stride;
   unsigned long long* trace;   // debug: phase timestamps of block (0,0) (may be null)
@@ -86,6 +90,17 @@ struct TopkParams {
   int algo;              // small-k fast path: 1 = one-level histogram + bucket counting sort, 0 = two-level select + radix ordering
   int nseg, seg_len;     // long rows: workgroup r handles segment r % nseg (seg_len keys) of row r / nseg and writes
                          // row-global indices to idx_out row r; L stays the full row length.  nseg <= 1: off
+};
+
+// gather-compaction done by the selecting workgroup itself (topk_gather_kernel): dense [B,H,k+w,128] outputs, 16-bit elements
+struct GatherTail {
+  const void* kptr;
+  const void* vptr;
+  void* k_out;
+  void* v_out;
+  int H, G, w, S;
+  int64_t ks_b, ks_h, ks_s;
+  int64_t vs_b, vs_h, vs_s;
 };
 
 struct SortParams {
@@ -184,7 +199,7 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st);
 hipError_t launch_logits2(int dtype, const LogitsParams& p, hipStream_t st);
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st);
 size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out);
-hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st);
+hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st, const GatherTail* tail = nullptr);
 // long-row merge helpers: candidate scores of the per-segment winners, and the final index look-up
 hipError_t launch_topk_merge_prep(int dtype, int rows, int L, int k, int nseg, int seg_len, const void* scores, int64_t scores_stride,
                                   const int32_t* cand_idx, void* cand_score, int64_t cand_stride, hipStream_t st);

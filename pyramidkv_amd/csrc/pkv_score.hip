@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 constexpr int FN_SPAN = 1024;              // positions computed per workgroup (256 threads x 4)
 constexpr int FN_OUT = FN_SPAN - 16;       // positions written per workgroup
 
-template <typename T>
+// PRE (w <= 8): the thread's 8 logits-row loads are issued BEFORE the row statistics are reduced, next to the partial
+// loads: one memory round trip on the critical path instead of two dependent ones (the statistics gate the arithmetic, not
+// the addresses).
+template <typename T, bool PRE>
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   __shared__ __attribute__((aligned(16))) uint16_t sc[FN_SPAN];
   __shared__ float rowM[64];
@@ -195,9 +198,25 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   PKV_FSTAMP(0);
   const unsigned long long t_start = PKV_WGTRACE(p) ? wall_clock64() : 0ull;
 
+  const int r0 = blockIdx.x * FN_OUT - 8;
+  const int s0 = r0 + tid * 4;
+  const bool in_row = s0 >= 0 && s0 < L;
+  const uint16_t* lgp = reinterpret_cast<const uint16_t*>(p.logits) + rowbase * (int64_t)p.Sp + (in_row ? s0 : 0);
   // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M).
   // 32 lanes per row, 8 rows per pass; every lane issues its (<= 8 per chunk) partial loads back to
   // back (clamped index, masked afterwards) so a pass costs ONE memory round trip, not nT/32.
+  float2 pv0[8];
+  u32x2 upre[8];
+  if (PRE) {
+    const float2* pr = p.partial + (rowbase + ((tid >> 5) < w ? (tid >> 5) : 0)) * p.nT;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = (tid & 31) + 32 * i;
+      pv0[i] = pr[t < p.nT ? t : p.nT - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) upre[j] = *reinterpret_cast<const u32x2*>(lgp + (int64_t)(j < w ? j : w - 1) * p.Sp);
+  }
   {
     const int sub = tid & 31;
     for (int r0 = 0; r0 < w; r0 += 8) {
@@ -210,7 +229,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int t = c0 + sub + 32 * i;
-          pv[i] = pr[t < p.nT ? t : p.nT - 1];
+          if (PRE && c0 == 0) pv[i] = pv0[i];
+          else pv[i] = pr[t < p.nT ? t : p.nT - 1];
           if (t >= p.nT) pv[i] = make_float2(-INFINITY, 0.f);
         }
         float mc = -INFINITY;
@@ -236,13 +256,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   __syncthreads();
   PKV_FSTAMP(1);
 
-  const int r0 = blockIdx.x * FN_OUT - 8;
-  const int s0 = r0 + tid * 4;
   const uint16_t pad = (p.pool_kind == 2) ? Elem<T>::neg_inf() : (uint16_t)0;
   uint16_t ov[4];
-  if (s0 >= 0 && s0 < L) {
+  if (in_row) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const uint16_t* lgp = reinterpret_cast<const uint16_t*>(p.logits) + rowbase * (int64_t)p.Sp + s0;
     for (int rb = 0; rb < w; rb += 8) {
       // 8 rows per pass, all loads first.  Rows past w are clamped (re-read row w-1) and weighted 0:
       // no control flow between the loads and their uses, so they stay batched (one round trip).
@@ -251,8 +268,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = rb + j < w ? rb + j : w - 1;
-        const u32x2* lp2 = reinterpret_cast<const u32x2*>(lgp + (int64_t)r * p.Sp);
-        const u32x2 t2 = *lp2;
+        u32x2 t2;
+        if (PRE) t2 = upre[j];                                    // PRE: w <= 8, a single pass (rb == 0)
+        else t2 = *reinterpret_cast<const u32x2*>(lgp + (int64_t)r * p.Sp);
         u[j] = make_uint2(t2.x, t2.y);
         M[j] = rowM[r];
         RZ[j] = rowS[r];
@@ -407,6 +425,8 @@ __global__ __launch_bounds__(256) void logits2_kernel(LogitsParams p) {
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b;
   const int64_t rowbase = ((int64_t)b * p.H + h0) * w;
   uint16_t* lg_out = reinterpret_cast<uint16_t*>(p.logits);
+  // raw buffer over the logits workspace (sc1 stores need the buffer form: cache-policy bits are an operand of the builtin)
+  const __amdgpu_buffer_rsrc_t lg_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits, 0, (int)p.logits_bytes, 0x00020000);
 
   u32x4 pre[8];
   auto issue = [&](int h) {
@@ -503,9 +523,21 @@ __global__ __launch_bounds__(256) void logits2_kernel(LogitsParams p) {
       if (PKV_ABLATE(p) == 2) { m_run[n] = m_new; continue; }   // measurement aid: no exponentials
       const float ms = (m_new == -INFINITY) ? 0.f : m_new;
       float sum = 0.f;
+      if (p.fexp) {
+        // The partial statistics only feed Z = sum_t l_t exp(m_t - M), whose fp32 summation order already differs from
+        // ATen's: the hardware exponential (v_exp_f32 on x*log2e - m*log2e, one FMA per logit, ~1e-6 relative per term,
+        // signs random) moves Z by ~1e-7 relative - below the order noise.  The probabilities themselves
+        // (finalize_kernel) keep the accurate exponential.
+        const float L2E = 1.44269502162933349609375f;
+        const float msl = ms * L2E;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sum += pkv_exp(xs[i] - ms);
-      l_run[n] = l_run[n] * pkv_exp(m_run[n] - ms) + sum;
+        for (int i = 0; i < 8; ++i) sum += __builtin_amdgcn_exp2f(fmaf(xs[i], L2E, -msl));
+        l_run[n] = l_run[n] * __builtin_amdgcn_exp2f(fmaf(m_run[n], L2E, -msl)) + sum;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += pkv_exp(xs[i] - ms);
+        l_run[n] = l_run[n] * pkv_exp(m_run[n] - ms) + sum;
+      }
       m_run[n] = m_new;
     }
     if (PKV_ABLATE(p) == 1 || PKV_ABLATE(p) == 2) continue;        // measurement aid: no logits store
@@ -519,7 +551,17 @@ __global__ __launch_bounds__(256) void logits2_kernel(LogitsParams p) {
         *reinterpret_cast<uint4*>(lg_out + ((int64_t)((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 128 + it) * 8) = v;
         continue;
       }
-      *reinterpret_cast<uint4*>(lg_out + (rowbase + row) * (int64_t)p.Sp + s_stage + ch * 8) = v;
+      uint16_t* dst = lg_out + (rowbase + row) * (int64_t)p.Sp + s_stage + ch * 8;
+      if (p.st_mode == 2) {
+        // write-through (sc1): the 16.8 MB of logits leave the XCD's L2 while the K stream is still running instead of
+        // as one write-back burst at the kernel boundary (MI355X_MICROARCH.md: a boundary costs + dirty bytes / 6 TB/s)
+        const uint32_t voff = (uint32_t)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(lg_out));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), lg_rsrc, voff, 0, 16);
+      } else if (p.st_mode == 1) {
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
+      } else {
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
     }
   }
   // per column: merge the 4 key-group lanes, then the 4 waves, one partial per (workgroup, row)
@@ -592,8 +634,9 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st) {
   const int L = p.S - p.w;
   dim3 grid((L + FN_OUT - 1) / FN_OUT, p.B * p.H);
-  if (dtype == 0) PKV_KLAUNCH(finalize_kernel<BF16>, grid, dim3(256), 0, st, p);
-  else PKV_KLAUNCH(finalize_kernel<F16>, grid, dim3(256), 0, st, p);
+  const bool pre = p.pre && p.w <= 8;
+  if (dtype == 0) { if (pre) PKV_KLAUNCH((finalize_kernel<BF16, true>), grid, dim3(256), 0, st, p); else PKV_KLAUNCH((finalize_kernel<BF16, false>), grid, dim3(256), 0, st, p); }
+  else { if (pre) PKV_KLAUNCH((finalize_kernel<F16, true>), grid, dim3(256), 0, st, p); else PKV_KLAUNCH((finalize_kernel<F16, false>), grid, dim3(256), 0, st, p); }
   return hipGetLastError();
 }
 
