@@ -219,11 +219,12 @@ def main():
     tokens_per_s = B * S * a.steps / el
     # ---- parity of the TIMED path: the step function that was just timed, layers 0 and 31, against the CPU oracle ----
     parity = None
-    if rank == 0 and not a.no_parity:
+    if not a.no_parity:
         keep = {0: None, NUM_LAYERS - 1: None}
-        one_step(keep)
+        one_step(keep)                       # every rank: the step holds the collective
         torch.cuda.synchronize()
-        parity = parity_block(keep, sets, ks, cap, a, S)
+        if rank == 0:
+            parity = parity_block(keep, sets, ks, cap, a, S)
 
     # ---- per-kernel device time over the same K steps (events on the dispatches, inside libpkv) ----
     N.prof_enable(True)
@@ -365,11 +366,12 @@ def parity_block(keep, sets, ks, cap, a, S):
     """The timed step's own outputs for layers 0 and 31 (first sequence, this rank's heads) against the CPU oracle
     (oracle.pyramidkv_update_kv / snapkv_update_kv == the reference's update_kv, canonical tie order) on the same tensors:
     fraction of heads whose selected index SET / index SEQUENCE / compacted K and V bits are the oracle's.  Where a
-    sequence differs, `order_within_1ulp` says whether the kernel's order is the oracle's order up to scores one unit in
-    the last place apart (the documented floor: ATen's own CPU softmax sums in a machine-dependent order)."""
+    sequence differs, `max_order_inversion_ulp` is the largest rise of the oracle's scores read in the kernel's order, in
+    units of the last place: two implementations whose scores agree within one unit can swap neighbours at most two units
+    apart (the documented floor: ATen's own CPU softmax sums in a machine-dependent order)."""
     from oracle import pkv_oracle as O
     res = {"checker": "oracle/pkv_oracle.py on the host CPU, same tensors as the timed step", "layers": {}}
-    agg = {"heads_identical_set": 1.0, "heads_identical_sequence": 1.0, "kv_bit_identical_heads": 1.0, "order_within_1ulp": True}
+    agg = {"heads_identical_set": 1.0, "heads_identical_sequence": 1.0, "kv_bit_identical_heads": 1.0, "max_order_inversion_ulp": 0}
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     for layer, got in sorted(keep.items()):
         q, k, v = (t[:1].cpu() for t in sets[layer % len(sets)])
@@ -387,14 +389,14 @@ def parity_block(keep, sets, ks, cap, a, S):
         # oracle scores read in the kernel's order must be non-increasing up to one unit in the last place
         sel = torch.gather(so, -1, ia).view(torch.int16).int()
         key = torch.where(sel < 0, -(sel & 0x7fff), sel)                       # monotone integer image of the 16-bit floats
-        ulp_ok = bool(((key[..., 1:] - key[..., :-1]).max() <= 1).item()) if key.shape[-1] > 1 else True
+        inv = max(0, int((key[..., 1:] - key[..., :-1]).max().item())) if key.shape[-1] > 1 else 0
         row = {"k": int(ks[layer]), "heads": int(seq_h.numel()),
                "heads_identical_set": float(set_h.float().mean()), "heads_identical_sequence": float(seq_h.float().mean()),
-               "kv_bit_identical_heads": float(kv_h.float().mean()), "order_within_1ulp": ulp_ok}
+               "kv_bit_identical_heads": float(kv_h.float().mean()), "max_order_inversion_ulp": inv}
         res["layers"][str(layer)] = row
         for f in ("heads_identical_set", "heads_identical_sequence", "kv_bit_identical_heads"):
             agg[f] = min(agg[f], row[f])
-        agg["order_within_1ulp"] = agg["order_within_1ulp"] and ulp_ok
+        agg["max_order_inversion_ulp"] = max(agg["max_order_inversion_ulp"], inv)
     res.update(agg)
     res["shape"] = "[1,%d,%d,128] %s, layers %s of the timed step" % (sets[0][0].shape[1], S, a.dtype, sorted(keep))
     return res

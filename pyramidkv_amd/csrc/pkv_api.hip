@@ -31,7 +31,6 @@ int logits_nt() { static int t = env_int("PKV_LOGITS_NT", 0); return t; }
 int logits_v2() { static int t = env_int("PKV_LOGITS_V2", 1); return t; }
 int logits_v2_nt() { static int t = env_int("PKV_LOGITS_NT", 1); return t; }
 int logits_v2_wgs() { static int t = env_int("PKV_LOGITS_V2_WGS", 0); return t; }   // target workgroup count, 0 = 8 per CU
-int fuse_gather() { static int t = env_int("PKV_FUSE_GATHER", 1); return t; }          // selection + gather in one launch when (k + w) <= 512
 int finalize_pre() { static int t = env_int("PKV_FIN_PRE", 1); return t; }           // finalize: row loads issued before the statistics
 int logits_fexp() { static int t = env_int("PKV_LOGITS_FEXP", 1); return t; }       // hardware exp2 in the partial statistics
 int logits_store() { static int t = env_int("PKV_LOGITS_ST", 2); return t; }        // 0 plain, 1 nontemporal, 2 write-through
@@ -275,7 +274,7 @@ size_t topk_tmp_bytes(int rows, int L, int k) {
 
 int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t stride, const int32_t* kpr,
             int32_t* idx, int64_t idx_stride, hipStream_t st, const void* cmax = nullptr, int64_t cmax_stride = 0,
-            void* tmp = nullptr, size_t tmp_bytes = 0, const GatherTail* tail = nullptr) {
+            void* tmp = nullptr, size_t tmp_bytes = 0) {
   if (L < 1 || k < 1 || k > L || rows < 1) return PKV_ERR_SHAPE;
   TopkParams tp;
   tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
@@ -293,11 +292,10 @@ int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t strid
     const size_t xw = (size_t)(tp.kpad > 8192 ? tp.kpad : 8192);
     tp.dual = lds >= (size_t)2 * 16 * tp.Lw + 4 * xw + 4 * 256 + 4 * 64 + 4 * 8192 ? 1 : 0;
     ProfScope ps(PKV_K_TOPK, st, true);
-    hipError_t e = launch_topk(dtype, nrows, tp, lds, st, tail);
+    hipError_t e = launch_topk(dtype, nrows, tp, lds, st);
     return e == hipSuccess ? PKV_OK : hip_fail(e);
   };
   if (topk_fits(L, k)) return launch(rows, L);
-  if (tail) return PKV_ERR_UNSUPPORTED;      // the fused form is only asked for when one workgroup holds the row (fuse_gather_ok)
   // long rows: top-k of every 32k segment (row-global indices, canonical order inside the segment), then the top-k of
   // the nseg*k winners.  The candidate list is segment-major, so position order == index order among equal scores and
   // the second selection reproduces (value desc, index asc) of the whole row.
@@ -360,20 +358,10 @@ int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, c
   rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
   int32_t* idx = idx_out ? idx_out : reinterpret_cast<int32_t*>(w + L.off_idx);
-  // small budgets: the selecting workgroup gathers its own rows (topk_gather_kernel) - no gather launch
-  const bool fuse = fuse_gather() && d->dtype != PKV_F32 && d->D == 128 && d->topk + d->window <= 512 &&
-                    topk_fits(d->S - d->window, d->topk);
-  GatherTail tail;
-  if (fuse) {
-    tail.kptr = k; tail.vptr = v; tail.k_out = k_out; tail.v_out = v_out;
-    tail.H = d->H; tail.G = d->kv_group; tail.w = d->window; tail.S = d->S;
-    tail.ks_b = d->k_stride[0]; tail.ks_h = d->k_stride[1]; tail.ks_s = d->k_stride[2];
-    tail.vs_b = d->v_stride[0]; tail.vs_h = d->v_stride[1]; tail.vs_s = d->v_stride[2];
-  }
   rc = do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx, d->topk, st,
                cm ? w + L.off_cmax : nullptr, L.Lp / 8,
-               w + L.off_tk, L.tk_bytes, fuse ? &tail : nullptr);
-  if (rc || fuse) return rc;
+               w + L.off_tk, L.tk_bytes);
+  if (rc) return rc;
   GatherParams g = make_gather(d, k, v, k_out, v_out);
   g.idx = idx; g.idx_stride = d->topk;
   return do_gather(g, d->topk + d->window, st);

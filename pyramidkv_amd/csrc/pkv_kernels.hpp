@@ -92,17 +92,6 @@ struct TopkParams {
                          // row-global indices to idx_out row r; L stays the full row length.  nseg <= 1: off
 };
 
-// gather-compaction done by the selecting workgroup itself (topk_gather_kernel): dense [B,H,k+w,128] outputs, 16-bit elements
-struct GatherTail {
-  const void* kptr;
-  const void* vptr;
-  void* k_out;
-  void* v_out;
-  int H, G, w, S;
-  int64_t ks_b, ks_h, ks_s;
-  int64_t vs_b, vs_h, vs_s;
-};
-
 struct SortParams {
   const void* scores;
   int64_t scores_stride;
@@ -199,7 +188,7 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st);
 hipError_t launch_logits2(int dtype, const LogitsParams& p, hipStream_t st);
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st);
 size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out);
-hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st, const GatherTail* tail = nullptr);
+hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st);
 // long-row merge helpers: candidate scores of the per-segment winners, and the final index look-up
 hipError_t launch_topk_merge_prep(int dtype, int rows, int L, int k, int nseg, int seg_len, const void* scores, int64_t scores_stride,
                                   const int32_t* cand_idx, void* cand_score, int64_t cand_stride, hipStream_t st);

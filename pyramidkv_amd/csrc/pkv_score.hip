@@ -214,8 +214,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
       const int t = (tid & 31) + 32 * i;
       pv0[i] = pr[t < p.nT ? t : p.nT - 1];
     }
+    // the partials (16 KB per head, shared by its 33 workgroups) come back first: the scheduler must not hoist the long
+    // row loads above them, or the reduction below waits for the rows (loads return in order)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) upre[j] = *reinterpret_cast<const u32x2*>(lgp + (int64_t)(j < w ? j : w - 1) * p.Sp);
+    __builtin_amdgcn_sched_barrier(0);
   }
   {
     const int sub = tid & 31;
@@ -500,21 +504,23 @@ __global__ __launch_bounds__(256) void logits2_kernel(LogitsParams p) {
         p01 = round_pack2<T>(x0, x1);
         p23 = round_pack2<T>(x2, x3);
         uint16_t o[4] = {(uint16_t)(p01 & 0xffffu), (uint16_t)(p01 >> 16), (uint16_t)(p23 & 0xffffu), (uint16_t)(p23 >> 16)};
+        bool dead[4] = {false, false, false, false};                                 // masked, or past the end of the row
         if (edge) {                                                                  // strict upper corner (:318-324)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int s = s_stage + key0 + r;
-            if (s >= L && (s - L) > rr_c) o[r] = Elem<T>::from_f32(Elem<T>::to_f32(o[r]) + fmin_v);
+            const bool masked = s >= L && (s - L) > rr_c;
+            if (masked) o[r] = Elem<T>::from_f32(Elem<T>::to_f32(o[r]) + fmin_v);
+            dead[r] = masked || s >= S;
           }
           p01 = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
           p23 = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
         }
         if (c < C) *reinterpret_cast<uint2*>(tile + c * LROW + key0) = make_uint2(p01, p23);
+        // In the statistics a masked entry is -inf: exp(finfo.min - M) is exactly 0 for every real maximum M, and a lane
+        // group that sees ONLY masked keys must not carry the finite finfo.min as its maximum (-max * log2e overflows)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = Elem<T>::to_f32(o[r]);
-          xs[t * 4 + r] = (edge && s_stage + key0 + r >= S) ? -INFINITY : x;
-        }
+        for (int r = 0; r < 4; ++r) xs[t * 4 + r] = dead[r] ? -INFINITY : Elem<T>::to_f32(o[r]);
       }
       float m_loc = xs[0];
 #pragma unroll

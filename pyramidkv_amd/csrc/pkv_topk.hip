@@ -146,7 +146,7 @@ __device__ __forceinline__ void radix_pass(const uint32_t* src, uint32_t* dst, u
 }
 
 template <typename T>
-__device__ __forceinline__ void topk_body(const TopkParams& p) {
+__global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -739,63 +739,6 @@ __device__ __forceinline__ void topk_body(const TopkParams& p) {
 #undef PKV_STAMP
 }
 
-template <typename T>
-__global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) { topk_body<T>(p); }
-
-// ------------------------------------------------------------------------------------------------
-// topk_gather_kernel: selection AND gather-compaction of one (b,h) by the same workgroup (small budgets).
-// At budget 128 a head's compacted K/V are ~240 rows x 512 B: as a separate launch the gather is a kernel boundary plus two
-// dependent round trips (indices, rows) for 0.7 us worth of bytes.  Here the 1024 threads that just selected the rows read
-// the workgroup's own indices back (L2 hit) and move (k + w) x {K, V} rows with <= 16 independent 16-B loads per lane: one
-// more round trip inside a workgroup that is resident anyway, no boundary.  Only for (k + w) <= 512 rows per head and
-// 256-byte rows; larger budgets want every CU (gather_kernel).  Reference pyramidkv_utils.py:334-346 in one launch.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(TK_THREADS) void topk_gather_kernel(TopkParams p, GatherTail g) {
-  topk_body<T>(p);
-  __syncthreads();                     // every index store of this workgroup has been issued and is visible to it (same CU)
-  const int tid = threadIdx.x;
-  const int bh = blockIdx.x;
-  const int b = bh / g.H, h = bh - b * g.H, hk = h / g.G;
-  const int k = p.k, nrows = k + g.w, L = g.S - g.w;
-  const int chunk = tid & 15, slot = tid >> 4;                  // 64 row slots x 16 lanes of 16 B
-  const int32_t* ib = p.idx_out + (int64_t)bh * p.idx_stride;
-  const uint16_t* kb = reinterpret_cast<const uint16_t*>(g.kptr) + (int64_t)b * g.ks_b + (int64_t)hk * g.ks_h + chunk * 8;
-  const uint16_t* vb = reinterpret_cast<const uint16_t*>(g.vptr) + (int64_t)b * g.vs_b + (int64_t)hk * g.vs_h + chunk * 8;
-  const int nj = (nrows + 63) >> 6;                             // workgroup-uniform, <= 8
-  int gi[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j < nj) {
-      const int r = j * 64 + slot;
-      gi[j] = __builtin_nontemporal_load(ib + (r < k ? r : k - 1));
-    }
-  }
-  u32x4 kd[8], vd[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j < nj) {
-      const int r = j * 64 + slot;
-      const int gsel = min(max(gi[j], 0), L - 1);
-      const int src = r < k ? gsel : (r < nrows ? L + (r - k) : 0);
-      kd[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (int64_t)src * g.ks_s));
-      vd[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (int64_t)src * g.vs_s));
-    }
-  }
-  uint16_t* ko = reinterpret_cast<uint16_t*>(g.k_out) + ((int64_t)bh * nrows) * 128 + chunk * 8;
-  uint16_t* vo = reinterpret_cast<uint16_t*>(g.v_out) + ((int64_t)bh * nrows) * 128 + chunk * 8;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j < nj) {
-      const int r = j * 64 + slot;
-      if (r < nrows) {
-        __builtin_nontemporal_store(kd[j], reinterpret_cast<u32x4*>(ko + (int64_t)r * 128));
-        __builtin_nontemporal_store(vd[j], reinterpret_cast<u32x4*>(vo + (int64_t)r * 128));
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // sort_rows_kernel: full stable descending sort of one score row (L <= 32768), one workgroup per row.
 // Two stable LSD radix passes over the 16-bit keys (low byte, then high byte): the input is in index
@@ -910,17 +853,7 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
 #undef PKV_SSTAMP
 }
 
-hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st, const GatherTail* tail) {
-  if (tail) {                                              // selection + gather-compaction in one launch (small budgets)
-    auto fg = dtype == 0 ? topk_gather_kernel<BF16> : topk_gather_kernel<F16>;
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
-    const GatherTail g = *tail;
-    PKV_KLAUNCH(fg, dim3(rows), dim3(TK_THREADS), lds, st, p, g);
-    return hipGetLastError();
-  }
+hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st) {
   auto fn = dtype == 0 ? topk_kernel<BF16> : topk_kernel<F16>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

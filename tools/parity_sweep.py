@@ -4,8 +4,8 @@
 (window 8, maxpool-7).  One table (round-2 review item 2c), written to gpurun_out/parity_sweep.json.
 
 Per point: heads whose selected index SET equals the oracle's, heads whose index SEQUENCE equals it, heads whose compacted
-K and V bits equal the oracle's, and whether every differing sequence is the oracle's order up to scores one unit in the
-last place apart.  The oracle sorts once per point (stable, value descending): its prefix is the canonical top-k of both
+K and V bits equal the oracle's, and the largest inversion of the oracle's scores read in the kernel's order (two
+implementations whose scores agree within one unit in the last place can swap neighbours up to two units apart).  The oracle sorts once per point (stable, value descending): its prefix is the canonical top-k of both
 budgets.  Test infrastructure: the oracle is the checker here, never the thing measured.
 """
 import json
@@ -50,11 +50,12 @@ def point(B, S, dt, seed):
         kr, vr = O.gather_compact(kc_, vc_, ridx, W)
         kv = (kc.cpu() == kr).flatten(2).all(-1) & (vc.cpu() == vr).flatten(2).all(-1)
         key = mono16(torch.gather(s, -1, ia))
-        ulp_ok = bool(((key[..., 1:] - key[..., :-1]).max() <= 1).item())
+        max_inv = int((key[..., 1:] - key[..., :-1]).max().item())       # oracle scores read in the kernel's order: largest rise, in ulps
+        ulp_ok = max_inv <= 2                                            # two neighbours each one ulp off in opposite directions
         n = seq.numel()
         rows.append({"B": B, "S": S, "dtype": str(dt).replace("torch.", ""), "budget": cap, "heads": n,
                      "heads_identical_set": int(st.sum()), "heads_identical_sequence": int(seq.sum()),
-                     "kv_bit_identical_heads": int(kv.sum()), "order_within_1ulp": ulp_ok,
+                     "kv_bit_identical_heads": int(kv.sum()), "order_within_2ulp": ulp_ok, "max_order_inversion_ulp": max(max_inv, 0),
                      "set_rate": round(float(st.float().mean()), 6), "sequence_rate": round(float(seq.float().mean()), 6)})
     return rows
 
@@ -79,7 +80,8 @@ def main():
         "set_rate": sum(r["heads_identical_set"] for r in rows) / max(tot, 1),
         "sequence_rate": sum(r["heads_identical_sequence"] for r in rows) / max(tot, 1),
         "kv_bit_identical_rate": sum(r["kv_bit_identical_heads"] for r in rows) / max(tot, 1),
-        "all_orders_within_1ulp": all(r["order_within_1ulp"] for r in rows),
+        "all_orders_within_2ulp": all(r["order_within_2ulp"] for r in rows),
+        "max_order_inversion_ulp": max(r["max_order_inversion_ulp"] for r in rows),
         "by_budget": {str(c): {"heads": sum(r["heads"] for r in rows if r["budget"] == c),
                                "sequence_rate": sum(r["heads_identical_sequence"] for r in rows if r["budget"] == c)
                                / max(1, sum(r["heads"] for r in rows if r["budget"] == c))} for c in (128, 2048)},
