@@ -180,10 +180,7 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 constexpr int FN_SPAN = 1024;              // positions computed per workgroup (256 threads x 4)
 constexpr int FN_OUT = FN_SPAN - 16;       // positions written per workgroup
 
-// PRE (w <= 8): the thread's 8 logits-row loads are issued BEFORE the row statistics are reduced, next to the partial
-// loads: one memory round trip on the critical path instead of two dependent ones (the statistics gate the arithmetic, not
-// the addresses).
-template <typename T, bool PRE>
+template <typename T>
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   __shared__ __attribute__((aligned(16))) uint16_t sc[FN_SPAN];
   __shared__ float rowM[64];
@@ -205,22 +202,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M).
   // 32 lanes per row, 8 rows per pass; every lane issues its (<= 8 per chunk) partial loads back to
   // back (clamped index, masked afterwards) so a pass costs ONE memory round trip, not nT/32.
-  float2 pv0[8];
-  u32x2 upre[8];
-  if (PRE) {
-    const float2* pr = p.partial + (rowbase + ((tid >> 5) < w ? (tid >> 5) : 0)) * p.nT;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int t = (tid & 31) + 32 * i;
-      pv0[i] = pr[t < p.nT ? t : p.nT - 1];
-    }
-    // the partials (16 KB per head, shared by its 33 workgroups) come back first: the scheduler must not hoist the long
-    // row loads above them, or the reduction below waits for the rows (loads return in order)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) upre[j] = *reinterpret_cast<const u32x2*>(lgp + (int64_t)(j < w ? j : w - 1) * p.Sp);
-    __builtin_amdgcn_sched_barrier(0);
-  }
   {
     const int sub = tid & 31;
     for (int r0 = 0; r0 < w; r0 += 8) {
@@ -233,8 +214,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int t = c0 + sub + 32 * i;
-          if (PRE && c0 == 0) pv[i] = pv0[i];
-          else pv[i] = pr[t < p.nT ? t : p.nT - 1];
+          pv[i] = pr[t < p.nT ? t : p.nT - 1];
           if (t >= p.nT) pv[i] = make_float2(-INFINITY, 0.f);
         }
         float mc = -INFINITY;
@@ -272,9 +252,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = rb + j < w ? rb + j : w - 1;
-        u32x2 t2;
-        if (PRE) t2 = upre[j];                                    // PRE: w <= 8, a single pass (rb == 0)
-        else t2 = *reinterpret_cast<const u32x2*>(lgp + (int64_t)r * p.Sp);
+        const u32x2 t2 = *reinterpret_cast<const u32x2*>(lgp + (int64_t)r * p.Sp);
         u[j] = make_uint2(t2.x, t2.y);
         M[j] = rowM[r];
         RZ[j] = rowS[r];
@@ -640,9 +618,8 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st) {
   const int L = p.S - p.w;
   dim3 grid((L + FN_OUT - 1) / FN_OUT, p.B * p.H);
-  const bool pre = p.pre && p.w <= 8;
-  if (dtype == 0) { if (pre) PKV_KLAUNCH((finalize_kernel<BF16, true>), grid, dim3(256), 0, st, p); else PKV_KLAUNCH((finalize_kernel<BF16, false>), grid, dim3(256), 0, st, p); }
-  else { if (pre) PKV_KLAUNCH((finalize_kernel<F16, true>), grid, dim3(256), 0, st, p); else PKV_KLAUNCH((finalize_kernel<F16, false>), grid, dim3(256), 0, st, p); }
+  if (dtype == 0) PKV_KLAUNCH(finalize_kernel<BF16>, grid, dim3(256), 0, st, p);
+  else PKV_KLAUNCH(finalize_kernel<F16>, grid, dim3(256), 0, st, p);
   return hipGetLastError();
 }
 
