@@ -194,12 +194,12 @@ __global__ __launch_bounds__(SP_THREADS) void select_parts_kernel(SelectParams p
       key[e] = (in_row && s0 + e < L) ? order_key<T>(r16) : 0u;          // real keys are >= 1
     }
   }
-  // ---- 13-bit histogram of the part's keys -> bin b* in which the count from the top reaches k_loc ----
-#pragma unroll
-  for (int e = 0; e < 8; ++e)
-    if (key[e] != 0u) atomicAdd(&hist[key[e] >> 3], 1u);
-  __syncthreads();                                                       // also: every read of `sc` is done, lbuf is free
-  {
+  // ---- exact threshold in two histogram rounds.  All 4096 keys of a part sit in a few dozen 13-bit bins (16-bit scores
+  //      of one softmax row span 2-3 binades), and LDS atomics on a hot address serialise (~1.7 cycles per lane-op: 7k
+  //      cycles for 4096 keys, measured in session 3).  Round 1 looks at ONE value per thread, the maximum of its 8-key
+  //      chunk: the k_loc-th largest chunk maximum x_c is a lower bound of the threshold (k_loc chunks hold a key >= x_c).
+  //      Round 2 histograms only the keys >= x_c (a few hundred), at FULL key resolution relative to x_c. ----
+  auto find_bin = [&](uint32_t need) -> uint32_t {        // bin b: count(bins > b) < need <= count(bins >= b); block-uniform result
     const uint4* h4 = reinterpret_cast<const uint4*>(hist) + tid * 4;    // bins 16*tid .. 16*tid + 15
     const uint4 a = h4[0], b = h4[1], c = h4[2], d = h4[3];
     const uint32_t hv[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
@@ -212,16 +212,37 @@ __global__ __launch_bounds__(SP_THREADS) void select_parts_kernel(SelectParams p
     uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl;   // bins of higher lanes of this wave
 #pragma unroll
     for (int w2 = 0; w2 < SP_THREADS / 64; ++w2) above += (w2 > wave) ? wtot[w2] : 0u;
-    if (above < (uint32_t)k_loc && (uint32_t)k_loc <= above + s16) {              // exactly one thread (nvalid >= k_loc keys)
+    if (above < need && need <= above + s16) {                                    // exactly one thread
 #pragma unroll
       for (int i = 15; i >= 0; --i) {
-        if (above < (uint32_t)k_loc && (uint32_t)k_loc <= above + hv[i]) misc[0] = (uint32_t)(tid * 16 + i);
+        if (above < need && need <= above + hv[i]) misc[0] = (uint32_t)(tid * 16 + i);
         above += hv[i];
       }
     }
+    __syncthreads();
+    return misc[0];
+  };
+  uint32_t cmx = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cmx = cmx > key[e] ? cmx : key[e];
+  const int nchunks = (nvalid + 7) >> 3;
+  uint32_t xc = 0;                                                       // round-1 bound; 0 = every key is a candidate
+  if (nchunks >= k_loc) {                                                // block-uniform
+    if (cmx != 0u) atomicAdd(&hist[cmx >> 3], 1u);
+    __syncthreads();                                                     // also: every read of `sc` is done, lbuf is free
+    xc = find_bin((uint32_t)k_loc) << 3;
+    if (cmx != 0u) atomicSub(&hist[cmx >> 3], 1u);                       // back to all-zero without a 32 KB clear
   }
   __syncthreads();
-  const uint32_t xstar = misc[0] << 3;                                   // at least k_loc keys are >= xstar
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (key[e] != 0u && key[e] >= xc) {
+      const uint32_t d = key[e] - xc;
+      atomicAdd(&hist[d < (uint32_t)SP_BINS - 1 ? d : (uint32_t)SP_BINS - 1], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t xstar = xc + find_bin((uint32_t)k_loc);                 // at least k_loc keys are >= xstar
   // ---- candidates (key >= xstar) in position order -> composites in LDS ----
   uint32_t cj = 0;
 #pragma unroll
@@ -271,6 +292,7 @@ hipError_t launch_select_parts(int dtype, const SelectParams& p, hipStream_t st)
 // as gather_kernel does.  Block 0 of a head also writes the index list (pkv_compress's idx_out / the workspace).
 // ------------------------------------------------------------------------------------------------
 constexpr int GM_THREADS = 1024;
+constexpr int GM_MAXPARTS = 16;                   // 65 536 positions / 4096 per part
 
 template <int CH>
 __global__ __launch_bounds__(GM_THREADS) void gather_merge_kernel(GatherParams p, const uint32_t* cand, int nparts, int32_t* idx_out,
@@ -291,21 +313,28 @@ __global__ __launch_bounds__(GM_THREADS) void gather_merge_kernel(GatherParams p
   __syncthreads();
   int kp2 = 1;
   while (kp2 <= k) kp2 <<= 1;                      // power of two > k
+  // One binary search per other list, ALL lists of a candidate in lockstep: every step issues its (<= 16) LDS reads back
+  // to back.  (List after list, the 7 x 8 dependent reads per candidate cost 6.8 us per gather workgroup - session 3.)
   for (int c = tid; c < n; c += GM_THREADS) {
     const uint32_t x = lists[c];
     if (x == 0u) continue;
     const int j = c / k;
-    int rank = c - j * k;
-    for (int j2 = 0; j2 < nparts; ++j2) {
-      if (j2 == j) continue;
-      const uint32_t* lj = lists + j2 * k;
-      int pos = 0;                                 // entries of list j2 greater than x (lists are descending, 0-padded)
-      for (int s = kp2 >> 1; s > 0; s >>= 1) {
-        const int q = pos + s;
-        if (q <= k && lj[q - 1] > x) pos = q;
+    int pos[GM_MAXPARTS];
+#pragma unroll
+    for (int j2 = 0; j2 < GM_MAXPARTS; ++j2) pos[j2] = 0;
+    for (int s = kp2 >> 1; s > 0; s >>= 1) {
+#pragma unroll
+      for (int j2 = 0; j2 < GM_MAXPARTS; ++j2) {
+        if (j2 < nparts) {                         // entries of list j2 greater than x (lists are descending, 0-padded)
+          const int q = pos[j2] + s;
+          if (q <= k && lists[j2 * k + q - 1] > x) pos[j2] = q;
+        }
       }
-      rank += pos;
     }
+    int rank = 0;
+#pragma unroll
+    for (int j2 = 0; j2 < GM_MAXPARTS; ++j2) rank += (j2 < nparts && j2 != j) ? pos[j2] : 0;
+    rank += c - j * k;                             // own list: the candidate's position
     if (rank < k) sel[rank] = (int32_t)(0xffffu - (x & 0xffffu));
   }
   __syncthreads();
