@@ -255,20 +255,10 @@ def main():
         }
 
     def kernel_rows(prof_, alg_):
-        """One roofline row per kernel that ran.  Small budgets (k <= 512) run the tail as TWO launches: select_parts_kernel
-        (score finish + exact per-part selection; row `finalize_select`, carrying finalize's and top-k's algorithmic bytes) and
-        gather_merge_kernel (row `gather`); no top-k dispatch exists then."""
+        """One roofline row per kernel that ran."""
         rows_ = {}
-        fused = prof_["topk"][1] == 0 and prof_["finalize"][1] > 0
         for name, by in alg_.items():
-            if fused and name == "topk":
-                continue
-            if fused and name == "finalize":
-                r = rl(prof_, "finalize", by + alg_["topk"], "finalize + per-part selection (one launch)")
-                if r:
-                    rows_["finalize_select"] = r
-                continue
-            r = rl(prof_, name, by, "merge + gather" if fused and name == "gather" else None)
+            r = rl(prof_, name, by)
             if r:
                 rows_[name] = r
         return rows_
@@ -508,15 +498,11 @@ def gqa_extra(P, N, rl, dt, dev, S, H, ks, steps):
     prof = N.prof_read(reset=True)
     N.prof_enable(False)
     k_mean = sum(ks) / NUM_LAYERS
-    fi_b, tk_b, ga_b = H * (W * S * E + (S - W) * E), H * ((S - W) * E + k_mean * 4), 4 * (k_mean + W) * D * E * H
-    fused = prof["topk"][1] == 0
     rows = {
         "logits_gqa4": rl(prof, "logits", (H // 4) * S * D * E + H * W * D * E, "logits (K/V un-expanded, kv_group 4: 8 KV heads)"),
-        "finalize_select_gqa4" if fused else "finalize_gqa4":
-            rl(prof, "finalize", fi_b + (tk_b if fused else 0),
-               "finalize + per-part selection (one launch, kv_group 4)" if fused else "finalize (kv_group 4)"),
-        "topk_gqa4": rl(prof, "topk", tk_b, "topk (kv_group 4)"),
-        "gather_gqa4": rl(prof, "gather", ga_b, "gather (kv_group 4: rows read from 8 KV heads)"),
+        "finalize_gqa4": rl(prof, "finalize", H * (W * S * E + (S - W) * E), "finalize (kv_group 4)"),
+        "topk_gqa4": rl(prof, "topk", H * ((S - W) * E + k_mean * 4), "topk (kv_group 4)"),
+        "gather_gqa4": rl(prof, "gather", 4 * (k_mean + W) * D * E * H, "gather (kv_group 4: rows read from 8 KV heads)"),
     }
     alg_total = sum(r["algorithmic_bytes"] for r in rows.values() if r)
     return {"unexpanded_gqa_tokens_per_s": round(S * steps / ge, 1),

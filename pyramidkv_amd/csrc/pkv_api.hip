@@ -118,18 +118,8 @@ size_t topk_tmp_bytes(int rows, int L, int k);
 
 struct WsLayout {
   int Sp, nT, Lp;
-  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_tk, tk_bytes, off_ada, off_ada_list, off_cand, off_rowstat, total;
+  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_tk, tk_bytes, off_ada, off_ada_list, off_rowstat, total;
 };
-
-// two-launch tail (select_parts_kernel + gather_merge_kernel): 16-bit scores, k <= 512, a row's positions fit the 16-bit
-// index of a composite, the merged lists fit the gather workgroup's LDS
-int fused_tail() { static int t = env_int("PKV_FUSED_TAIL", 1); return t; }
-int select_nparts(int L) { return (L + select_part_len() - 1) / select_part_len(); }
-bool fused_tail_ok(const pkv_desc* d) {
-  const int L = d->S - d->window;
-  return fused_tail() && d->dtype != PKV_F32 && d->topk >= 1 && d->topk <= 512 && L <= 65536 &&
-         ((size_t)select_nparts(L) + 1) * d->topk * 4 <= 150 * 1024;
-}
 
 WsLayout ws_layout(const pkv_desc* d) {
   WsLayout w;
@@ -149,16 +139,13 @@ WsLayout ws_layout(const pkv_desc* d) {
   w.off_tk = o;      o = align_up(o + w.tk_bytes, 256);
   w.off_ada = o;     o = align_up(o + 1024 + (size_t)2 * d->H * 256 * 4, 256);                 // Ada-SnapKV budget scratch (pkv_ada_select)
   w.off_ada_list = o; o = align_up(o + (size_t)d->H * align_up((size_t)(d->topk > 0 ? d->topk : 1), 8) * 2, 256);   // looked-up top-M lists
-  w.off_cand = o;
-  if (d->topk >= 1 && d->topk <= 512)                                                       // part lists of the two-launch tail
-    o = align_up(o + (size_t)d->B * d->H * select_nparts(d->S - d->window) * d->topk * 4, 256);
   w.off_rowstat = o; o = align_up(o + (size_t)d->B * d->H * d->S * sizeof(float2), 256);   // H2O only
   w.total = o;
   return w;
 }
 
 int do_score_window(const pkv_desc* d, const void* q, const void* k, void* scores, int64_t stride,
-                    char* ws, const WsLayout& L, hipStream_t st, bool want_cmax = false, int* logits_only_nT = nullptr) {
+                    char* ws, const WsLayout& L, hipStream_t st, bool want_cmax = false) {
   LogitsParams lp;
   lp.q = q; lp.k = k;
   lp.logits = ws + L.off_logits;
@@ -225,7 +212,6 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     hipError_t e = launch_logits(d->dtype, lp, st);
     if (e != hipSuccess) return hip_fail(e);
   }
-  if (logits_only_nT) { *logits_only_nT = nT_used; return PKV_OK; }      // the caller finishes the scores itself (two-launch tail)
   FinalizeParams fp;
   fp.logits = lp.logits; fp.partial = lp.partial;
   fp.scores = scores; fp.scores_stride = stride;
@@ -368,27 +354,6 @@ int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, c
   void* scores = w + L.off_scores;
   const bool cm = !h2o && d->dtype != PKV_F32 && env_int("PKV_TOPK_CMAX", 1) != 0;   // chunk maxima feed the top-k prefilter
   if (h2o && d->D != 128) return PKV_ERR_UNSUPPORTED;
-  if (!h2o && fused_tail_ok(d)) {
-    // small budgets: K scan -> (score finish + per-part selection) -> (merge + gather): two launches after the scan
-    int nT_used = 0;
-    rc = do_score_window(d, q, k, scores, L.Lp, w, L, st, false, &nT_used);
-    if (rc) return rc;
-    SelectParams sp;
-    sp.logits = w + L.off_logits; sp.partial = reinterpret_cast<const float2*>(w + L.off_partial);
-    sp.cand = reinterpret_cast<uint32_t*>(w + L.off_cand);
-    sp.B = d->B; sp.H = d->H; sp.S = d->S; sp.w = d->window; sp.Sp = L.Sp; sp.nT = nT_used;
-    sp.pool_kind = d->pool_kind; sp.pool_kernel = d->pool_kind == PKV_POOL_NONE ? 1 : d->pool_kernel; sp.reduce = d->reduce;
-    sp.k = d->topk; sp.nparts = select_nparts(d->S - d->window);
-    {
-      ProfScope ps(PKV_K_FINALIZE, st, true);
-      hipError_t e = launch_select_parts(d->dtype, sp, st);
-      if (e != hipSuccess) return hip_fail(e);
-    }
-    GatherParams g = make_gather(d, k, v, k_out, v_out);
-    ProfScope ps(PKV_K_GATHER, st, true);
-    hipError_t e = launch_gather_merge(g, sp.cand, sp.nparts, idx_out, d->topk, st);
-    return e == hipSuccess ? PKV_OK : hip_fail(e);
-  }
   rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
   int32_t* idx = idx_out ? idx_out : reinterpret_cast<int32_t*>(w + L.off_idx);

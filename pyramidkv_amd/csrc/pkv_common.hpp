@@ -120,6 +120,11 @@ __device__ __forceinline__ pkv_f32x2 pkv_exp_pair(pkv_f32x2 x) {
   return pkv_f32x2{ldexpf(__builtin_amdgcn_exp2f(f.x), (int)n.x), ldexpf(__builtin_amdgcn_exp2f(f.y), (int)n.y)};
 }
 
+// exp(x) for the merge of softmax PARTIAL statistics (x = m_t - M <= 0, or -inf): hardware v_exp_f32 on x * log2(e), ~1e-6
+// relative.  The merged Z = sum_t l_t exp(m_t - M) only enters the probabilities through 1/Z, and its fp32 summation order
+// already differs from ATen's by as much; the probabilities themselves use pkv_exp.
+__device__ __forceinline__ float pkv_exp_stat(float x) { return __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f); }
+
 // correctly rounded x / c for a loop-invariant c (rc = RN(1/c)): one Newton-Markstein correction step.
 __device__ __forceinline__ float div_const(float x, float c, float rc) {
   const float q = x * rc;

@@ -91,16 +91,6 @@ struct TopkParams {
                          // row-global indices to idx_out row r; L stays the full row length.  nseg <= 1: off
 };
 
-// score finish + per-part exact selection in one launch (pkv_select.hip); parts of select_part_len() positions
-struct SelectParams {
-  const void* logits;        // [B*H*w][Sp] model dtype (K scan output)
-  const float2* partial;     // [B*H*w][nT]
-  uint32_t* cand;            // [B*H][nparts][k] composites key<<16 | (0xffff - position), descending, 0-padded
-  int B, H, S, w, Sp, nT;
-  int pool_kind, pool_kernel, reduce;
-  int k, nparts;
-};
-
 struct SortParams {
   const void* scores;
   int64_t scores_stride;
@@ -205,10 +195,6 @@ hipError_t launch_topk_merge_finish(int rows, int k, const int32_t* cand_idx, in
                                     int64_t idx_stride, hipStream_t st);
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);
 hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
-int select_part_len();
-hipError_t launch_select_parts(int dtype, const SelectParams& p, hipStream_t st);
-hipError_t launch_gather_merge(const GatherParams& p, const uint32_t* cand, int nparts, int32_t* idx_out, int64_t idx_stride,
-                               hipStream_t st);
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
 hipError_t launch_ada_metadata(int H, int w, const int32_t* cap, int32_t* head_lens, int32_t* cu_klen, hipStream_t st,
                                int32_t* cu_headlens = nullptr);

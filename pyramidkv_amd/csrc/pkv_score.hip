@@ -226,12 +226,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
         float zc = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float t = pv[i].y * pkv_exp(pv[i].x - mn);       // exp(-inf - mn) == 0
+          const float t = pv[i].y * pkv_exp_stat(pv[i].x - mn);       // exp(-inf - mn) == 0
           zc += (pv[i].x != -INFINITY) ? t : 0.f;
         }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) zc += __shfl_xor(zc, o, 64);
-        z = (m == -INFINITY ? 0.f : z * pkv_exp(m - mn)) + zc;
+        z = (m == -INFINITY ? 0.f : z * pkv_exp_stat(m - mn)) + zc;
         m = mn;
       }
       if (live && sub == 0) { rowM[r] = m; rowS[r] = 1.0f / z; }   // ATen CPU softmax: x * (1 / sum)
@@ -313,25 +313,31 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
       v[i * 4 + 2] = Elem<T>::to_f32((uint16_t)(t.y & 0xffffu));
       v[i * 4 + 3] = Elem<T>::to_f32((uint16_t)(t.y >> 16));
     }
-    if (p.pool_kind == 2) {                                                      // max_pool1d, -inf padding (:331)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
+    // the runners' kernel sizes (run_longbench.py: maxpool 7, avgpool 5) get compile-time windows: the generic loop is 17
+    // predicated taps per output, ~70 instructions per position
+    auto pool_at = [&](int e, int hw, bool is_max) -> uint16_t {
+      if (is_max) {                                                              // max_pool1d, -inf padding (:331)
         float m = -INFINITY;
 #pragma unroll
         for (int j = -8; j <= 8; ++j)
-          if (j >= -half && j <= half) m = fmaxf(m, v[8 + e + j]);
-        res[e] = Elem<T>::from_f32(m);
+          if (j >= -hw && j <= hw) m = fmaxf(m, v[8 + e + j]);
+        return Elem<T>::from_f32(m);
       }
-    } else {                                                                     // avg_pool1d, zero padding, / kernel (:329)
-      const float ks = (float)p.pool_kernel;
+      float sum = 0.f;                                                           // avg_pool1d, zero padding, / kernel (:329)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float sum = 0.f;
+      for (int j = -8; j <= 8; ++j)
+        if (j >= -hw && j <= hw) sum += v[8 + e + j];                            // left-to-right fp32 sum
+      return Elem<T>::from_f32(sum / (float)(2 * hw + 1));
+    };
+    if (p.pool_kind == 2 && half == 3) {
 #pragma unroll
-        for (int j = -8; j <= 8; ++j)
-          if (j >= -half && j <= half) sum += v[8 + e + j];                      // left-to-right fp32 sum
-        res[e] = Elem<T>::from_f32(sum / ks);
-      }
+      for (int e = 0; e < 4; ++e) res[e] = pool_at(e, 3, true);
+    } else if (p.pool_kind == 1 && half == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) res[e] = pool_at(e, 2, false);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) res[e] = pool_at(e, half, p.pool_kind == 2);
     }
   }
   // per-chunk maxima (8 consecutive positions = an even/odd lane pair) for the top-k prefilter
