@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-3 full GPU session: everything profiles/r03 is built from (tools/collect_r03.py copies the judged artefacts).
+#   SKIP_PYTEST=1  the suite ran in its own gpurun call      SKIP_H2O=1  no H2O profile / counter passes
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/full3
+rm -rf $O; mkdir -p $O
+cd $R
+if [ -z "${SKIP_PYTEST:-}" ]; then
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 --durations=5 > $O/pytest.txt 2>&1
+echo "pytest exit $?" >> $O/pytest.txt
+fi
+cp gpurun_out/parity_report.json $O/parity_report.json 2>/dev/null
+./tools/bw_probe > $O/bw_probe.json 2> $O/bw_probe.err
+# HBM traffic counters first: the bench line attaches them when they belong to the current kernel sources
+(cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-parity > $O/pmc_fetch.log 2>&1 ; timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-parity > $O/pmc_write.log 2>&1 ; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_gather_fetch -- python $R/tools/gather_pmc.py > $O/pmc_gather_fetch.log 2>&1 ; timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_gather_write -- python $R/tools/gather_pmc.py > $O/pmc_gather_write.log 2>&1 ; python $R/tools/pmc_summary.py $O $O/pmc_traffic.json > $O/pmc_summary.log 2>&1)
+mkdir -p $R/profiles/r03; cp $O/pmc_traffic.json $R/profiles/r03/pmc_traffic.json 2>/dev/null
+# the driver's command
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+echo "bench exit $?" >> $O/bench.err
+timeout 600 python tools/policy_bench.py > $O/policy_bench.json 2> $O/policy_bench.err
+timeout 600 python tools/ada_bench.py > $O/ada_bench.json 2> $O/ada_bench.err
+timeout 900 python tools/parity_sweep.py > $O/parity_sweep.log 2>&1; cp gpurun_out/parity_sweep.json $O/parity_sweep.json 2>/dev/null
+# RCCL with nranks = 1 (process group nccl, one all-gather per prefill) and the self-launched N = 2 code path through gloo
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_rccl_n1.json 2> $O/bench_rccl_n1.log
+PKV_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_n2_gloo_selflaunch.json 2> $O/bench_n2_gloo_selflaunch.log
+timeout 120 python bench.py --gpus 2 --steps 3 --warmup 1 > $O/bench_n2_nccl_one_gpu.json 2> $O/bench_n2_nccl_one_gpu.log; echo "exit $? (2 = refused: one GPU visible, no silent gloo)" >> $O/bench_n2_nccl_one_gpu.log
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_headline -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-parity > $O/rocprof_headline.log 2>&1
+echo "rocprof headline exit $?" >> $O/rocprof_headline.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof.log 2>&1
+echo "rocprof exit $?" >> $O/rocprof.log
+python $R/__graft_entry__.py smoke > $O/smoke.log 2>&1
+echo "smoke exit $?" >> $O/smoke.log
+if [ -z "${SKIP_H2O:-}" ]; then
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_h2o -- python $R/tools/h2o_only.py 32768 > $O/prof_h2o.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_h2o_a -- python $R/tools/h2o_only.py 32768 > $O/pmc_h2o_a.log 2>&1
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_h2o_c -- python $R/tools/h2o_only.py 32768 > $O/pmc_h2o_c.log 2>&1
+fi
+cd $R
+tail -4 $O/pytest.txt 2>/dev/null; head -c 400 $O/bench.json; echo; tail -2 $O/bench.err; tail -1 $O/parity_sweep.log
