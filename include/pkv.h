@@ -60,7 +60,7 @@ typedef struct pkv_desc {
   int64_t q_stride[3];  /* element strides of q for b,h,s */
   int64_t k_stride[3];
   int64_t v_stride[3];
-  int32_t window;       /* w = window_size, 1..64 */
+  int32_t window;       /* w = window_size, 1..128 (scoring entry points; kv_group * window <= 256) */
   int32_t pool_kind;    /* pkv_pool */
   int32_t pool_kernel;  /* odd, <= 17; padding = kernel/2, stride 1 (pyramidkv_utils.py:328-331) */
   int32_t reduce;       /* pkv_reduce: SUM for SnapKV/PyramidKV (:327), MEAN for AdaKV/HeadKV (:661) */
@@ -164,6 +164,18 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
                         const int32_t* top_idx, int64_t idx_stride, int32_t base_capacity, double floor_ratio,
                         int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens, int32_t* cu_klen,
                         void* ws, size_t ws_bytes, pkv_stream_t stream);
+
+/* The same budgets from the UN-SORTED score rows alone (no sort, no top-M list): what :706-719 consume of the order is, per
+ * head, the sum of its `base` largest scores (:710) and how many of its adaptive scores lie above / at the global threshold
+ * (:712-717) - selections and counts, computed by histograms over the whole row.  For H*base > 4096 (budget 2048), where
+ * min(L, H*base) is the whole row.  scores: dtype [H][scores_stride], rows of length L <= 65536.  cu_headlens (optional,
+ * int32 [H]): inclusive prefix of head_lens (:687).  host_mirror (optional): device-visible PINNED HOST int32 [H+1]: gets the
+ * capacities, then host_seq in word H (release, system scope) - the host polls it instead of copy + stream synchronise.
+ * The gather then needs, per head, its first cap_h entries of the canonical order: pkv_topk with k_per_row = head_capacity. */
+int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores, int64_t scores_stride, int32_t base_capacity,
+                        double floor_ratio, int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens,
+                        int32_t* cu_klen, int32_t* cu_headlens, int32_t* host_mirror, int32_t host_seq, void* ws, size_t ws_bytes,
+                        pkv_stream_t stream);
 
 /* Head-sharded Ada-SnapKV: the budget of :712-717 couples ALL heads, so the ranks exchange one
  * thing - every head's ADAPTIVE list (:709-711: sorted scores x sum(top base)/sum(all), model dtype), first M entries.

@@ -64,6 +64,7 @@ def _load():
         "pkv_sort_rows": (C.c_int, [i32, i32, i32, vp, i64, vp, vp, vp]),
         "pkv_ada_budget": (C.c_int, [i32, i32, i32, vp, i32, C.c_double, i32, vp, vp, sz, vp]),
         "pkv_ada_budget_topm": (C.c_int, [i32, i32, i32, i32, vp, i64, vp, i64, i32, C.c_double, i32, i32, vp, vp, vp, vp, sz, vp]),
+        "pkv_ada_budget_rows": (C.c_int, [i32, i32, i32, vp, i64, i32, C.c_double, i32, i32, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
         "pkv_ada_adaptive_lists": (C.c_int, [i32, i32, i32, i32, vp, i64, vp, i64, i32, i32, vp, vp, sz, vp]),
         "pkv_ada_select": (C.c_int, [dp, vp, vp, i32, C.c_double, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
         "pkv_ada_metadata": (C.c_int, [i32, i32, vp, vp, vp, vp]),

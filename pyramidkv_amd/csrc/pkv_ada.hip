@@ -19,6 +19,7 @@
 // is staged in LDS, and the sum over ALL scores of the row (:710) is taken from the row itself.
 #include "pkv_common.hpp"
 #include "pkv_kernels.hpp"
+#include "pkv_radix.hpp"
 
 namespace pkv {
 
@@ -248,6 +249,193 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Un-sorted variants (BudgetParams::unsorted): the same cum_hi / cum_lo tables straight from the score rows, by counting.
+// Used when H * base > 4096 (budget 2048: M = min(L, H * base) is the whole row and a top-M list is a full sort).
+// What :706-719 need of the order is two counts per head - how many adaptive scores lie above the global threshold, how
+// many equal it - and one sum, the `base` largest scores of the row (:710).  Both are selections, not sorts:
+//   ada_stats_u  one 1024-thread workgroup per head, the row in registers (<= 64 keys per thread):
+//                exact two-level (8+8 bit) radix select of the base-th largest RAW score -> sum of the top `base` (ties
+//                contribute the threshold value) and the row total -> ratio (:710); then the histogram of the ADAPTIVE keys'
+//                high byte, suffix-summed into cum_hi;
+//   ada_lo_u     after the global high byte b1 is known: histogram of the low byte of the adaptive keys in bin b1 -> cum_lo.
+// ada_final_kernel is shared.  Counting is over the WHOLE row (no clamp at M), i.e. the reference's definition itself.
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float key_value(uint32_t key) {     // inverse of order_key for finite scores
+  const uint32_t k = key - KeyBias<T>::v;
+  const uint16_t h = (k & 0x8000u) ? (uint16_t)(k ^ 0x8000u) : (uint16_t)(~k);
+  return Elem<T>::to_f32(h);
+}
+
+template <typename T, int NIT>
+__device__ __forceinline__ void load_row_regs(const uint16_t* row, int L, int Lw, int tid, U4 (&raw)[NIT]) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const bool vec = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int base = wave * Lw + j * 512 + lane * 8;
+    if (j * 512 < Lw) {
+      if (vec && base + 8 <= ((L + 7) & ~7)) {
+        raw[j].v = *reinterpret_cast<const uint4*>(row + (base < L ? base : 0));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[j].h[e] = row[base + e < L ? base + e : L - 1];
+      }
+    }
+  }
+}
+
+// one histogram pass over the thread's keys: X[digit][32 spread slots] += 1 for every key that `take`s; zeroes X first
+template <int NIT, typename F>
+__device__ __forceinline__ void hist_pass(uint32_t* X, int Lw, int L, int tid, F&& digit_of) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const uint32_t inc = lane < 32 ? 1u : 65536u;
+  const int cslot = lane & 31;
+  for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) X[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    if (j * 512 < Lw) {
+      const int base = wave * Lw + j * 512 + lane * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (base + e < L) {
+          const int d = digit_of(j, e);
+          if (d >= 0) atomicAdd(&X[d * 32 + cslot], inc);
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(TK_THREADS) void ada_stats_u_kernel(BudgetParams p, AdaWs ws) {
+  constexpr int NIT = 8;                                // <= 64 keys per thread: rows up to 65 536 scores
+  __shared__ __attribute__((aligned(16))) uint32_t X[TK_CNT_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t hist[256];
+  __shared__ int misc[4];
+  __shared__ double red[2][TK_WAVES];
+  __shared__ float s_ratio;
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = p.Lrow;
+  int Lw = ((L + TK_WAVES - 1) / TK_WAVES + 511) / 512 * 512;
+  const uint16_t* row = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)h * p.scores_stride;
+  U4 raw[NIT];
+  load_row_regs<T, NIT>(row, L, Lw, tid, raw);
+  float ratio = 1.0f;
+  if (p.normalize) {
+    // base-th largest raw score: high byte, then low byte inside that bin
+    hist_pass<NIT>(X, Lw, L, tid, [&](int j, int e) { return (int)(order_key<T>(raw[j].h[e]) >> 8); });
+    select_bin(X, hist, (uint32_t)p.base, &misc[0], &misc[1], tid);
+    __syncthreads();
+    const int b1 = misc[0], above1 = misc[1];
+    hist_pass<NIT>(X, Lw, L, tid, [&](int j, int e) { const uint32_t k = order_key<T>(raw[j].h[e]); return (int)(k >> 8) == b1 ? (int)(k & 255u) : -1; });
+    select_bin(X, hist, (uint32_t)(p.base - above1), &misc[2], &misc[3], tid);
+    __syncthreads();
+    const uint32_t Tk = ((uint32_t)b1 << 8) | (uint32_t)misc[2];
+    const int n_gt = above1 + misc[3];
+    double st = 0.0, sa = 0.0;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      if (j * 512 < Lw) {
+        const int base = wave * Lw + j * 512 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (base + e < L) {
+            const double x = (double)Elem<T>::to_f32(raw[j].h[e]);
+            sa += x;
+            if (order_key<T>(raw[j].h[e]) > Tk) st += x;
+          }
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { st += __shfl_xor(st, o, 64); sa += __shfl_xor(sa, o, 64); }
+    if (lane == 0) { red[0][wave] = st; red[1][wave] = sa; }
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0, a = 0.0;
+      for (int w2 = 0; w2 < TK_WAVES; ++w2) { t += red[0][w2]; a += red[1][w2]; }
+      t += (double)(p.base - n_gt) * (double)key_value<T>(Tk);          // the ties at the threshold that belong to the top `base`
+      const float tq = Elem<T>::to_f32(Elem<T>::from_f32((float)t));    // .sum() result in model dtype (:710)
+      const float aq = Elem<T>::to_f32(Elem<T>::from_f32((float)a));
+      s_ratio = Elem<T>::to_f32(Elem<T>::from_f32(tq / aq));            // model-dtype division (:710)
+      ws.ratio[h] = s_ratio;
+    }
+    __syncthreads();
+    ratio = s_ratio;
+  } else if (tid == 0) {
+    ws.ratio[h] = 1.0f;
+  }
+  const int norm = p.normalize;
+  hist_pass<NIT>(X, Lw, L, tid, [&](int j, int e) { return (int)(adaptive_key<T>(raw[j].h, e, ratio, norm) >> 8); });
+  reduce_counters(X, hist, tid);
+  __syncthreads();
+  {                                                      // cum_hi[b] = sum of bins b..255: suffix over 4 waves of 64 bins
+    const uint32_t c = tid < 256 ? hist[tid] : 0u;
+    const uint32_t incl = wave_incl_scan_u32(c);
+    const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t suf = wtot - incl + c;                      // bins tid .. end of this wave's 64
+    if (lane == 0 && wave < 4) misc[wave] = (int)wtot;
+    __syncthreads();
+    if (tid < 256) {
+      for (int w2 = wave + 1; w2 < 4; ++w2) suf += (uint32_t)misc[w2];
+      ws.cum_hi[h * 256 + tid] = (int32_t)suf;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TK_THREADS) void ada_lo_u_kernel(BudgetParams p, AdaWs ws) {
+  constexpr int NIT = 8;
+  __shared__ __attribute__((aligned(16))) uint32_t X[TK_CNT_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t hist[256];
+  __shared__ int64_t s_sum[256];
+  __shared__ int s_b;
+  __shared__ int misc[4];
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = p.Lrow;
+  int Lw = ((L + TK_WAVES - 1) / TK_WAVES + 511) / 512 * 512;
+  const uint16_t* row = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)h * p.scores_stride;
+  U4 raw[NIT];
+  load_row_regs<T, NIT>(row, L, Lw, tid, raw);
+  const int64_t total = (int64_t)p.H * p.base;
+  // global high byte (the 256 sums over the heads; threads 0..255)
+  if (tid < 256) {
+    int64_t s = 0;
+    for (int h0 = 0; h0 < p.H; h0 += 32) {
+      int32_t v[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) v[j] = ws.cum_hi[(h0 + j < p.H ? h0 + j : p.H - 1) * 256 + tid];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) s += (h0 + j < p.H) ? v[j] : 0;
+    }
+    s_sum[tid] = s;
+  }
+  __syncthreads();
+  if (tid < 256 && s_sum[tid] >= total && (tid == 255 || s_sum[tid + 1] < total)) s_b = tid;
+  __syncthreads();
+  const int b1 = s_b;
+  const float ratio = ws.ratio[h];
+  const int norm = p.normalize;
+  hist_pass<NIT>(X, Lw, L, tid, [&](int j, int e) { const uint32_t k = adaptive_key<T>(raw[j].h, e, ratio, norm); return (int)(k >> 8) == b1 ? (int)(k & 255u) : -1; });
+  reduce_counters(X, hist, tid);
+  __syncthreads();
+  const int above = b1 < 255 ? ws.cum_hi[h * 256 + b1 + 1] : 0;       // adaptive keys of this head in higher bins
+  {
+    const uint32_t c = tid < 256 ? hist[tid] : 0u;
+    const uint32_t incl = wave_incl_scan_u32(c);
+    const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t suf = wtot - incl + c;
+    if (lane == 0 && wave < 4) misc[wave] = (int)wtot;
+    __syncthreads();
+    if (tid < 256) {
+      for (int w2 = wave + 1; w2 < 4; ++w2) suf += (uint32_t)misc[w2];
+      ws.cum_lo[h * 256 + tid] = (int32_t)suf + above;
+    }
+  }
+}
+
 __global__ void ada_metadata_kernel(int H, int w, const int32_t* cap, int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int run = 0;
@@ -278,6 +466,18 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+  }
+  if (p.unsorted) {               // counts straight from the un-sorted score rows (no top-M list, no sort)
+    if (dtype == 0) {
+      hipLaunchKernelGGL(ada_stats_u_kernel<BF16>, dim3(p.H), dim3(TK_THREADS), 0, st, p, ws);
+      hipLaunchKernelGGL(ada_lo_u_kernel<BF16>, dim3(p.H), dim3(TK_THREADS), 0, st, p, ws);
+    } else {
+      hipLaunchKernelGGL(ada_stats_u_kernel<F16>, dim3(p.H), dim3(TK_THREADS), 0, st, p, ws);
+      hipLaunchKernelGGL(ada_lo_u_kernel<F16>, dim3(p.H), dim3(TK_THREADS), 0, st, p, ws);
+    }
+    hipLaunchKernelGGL(ada_final_kernel, dim3(1), dim3(256), 0, st, p, ws, omf, p.window, p.head_lens_out, p.cu_klen_out,
+                       p.cu_headlens_out);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL(k_stats, dim3(p.H), dim3(256), lds, st, p, ws);
   if (p.adaptive_out) return hipGetLastError();

@@ -99,7 +99,7 @@ int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true, bool f32_
   if (d->B < 1 || d->H < 1 || d->S < 2) return PKV_ERR_SHAPE;
   if (d->kv_group < 1 || d->H % d->kv_group) return PKV_ERR_SHAPE;
   if (d->window < 1 || d->window >= d->S) return PKV_ERR_SHAPE;
-  if (scoring && (d->window > 64 || d->kv_group * d->window > 256)) return PKV_ERR_UNSUPPORTED;
+  if (scoring && (d->window > 128 || d->kv_group * d->window > 256)) return PKV_ERR_UNSUPPORTED;
   if (need_topk && (d->topk < 1 || d->topk > d->S - d->window)) return PKV_ERR_SHAPE;
   if (d->pool_kind < 0 || d->pool_kind > 2) return PKV_ERR_SHAPE;
   if (d->pool_kind != PKV_POOL_NONE) {
@@ -567,7 +567,7 @@ int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, 
   bp.sorted_val = sorted_val; bp.H = H; bp.L = L; bp.base = base_capacity;
   bp.one_minus_floor = (float)(1.0 - floor_ratio);                    // python double, then the fp32 scalar of :719
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);     // int(base_capacity * floor_ratio) (:632)
-  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr;
+  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr; bp.unsorted = 0;
   bp.window = 0; bp.head_lens_out = nullptr; bp.cu_klen_out = nullptr; bp.cu_headlens_out = nullptr;
   bp.host_mirror = nullptr; bp.host_seq = 0; bp.adaptive_out = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -594,9 +594,33 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
   bp.Lrow = L; bp.H = H; bp.L = M; bp.base = base_capacity;
   bp.one_minus_floor = (float)(1.0 - floor_ratio);
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
-  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr;
+  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr; bp.unsorted = 0;
   bp.window = window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = nullptr;
   bp.host_mirror = nullptr; bp.host_seq = 0; bp.adaptive_out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(PKV_K_BUDGET, st);
+  hipError_t e = launch_budget(dtype, bp, st);
+  return e == hipSuccess ? PKV_OK : hip_fail(e);
+}
+
+int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores, int64_t scores_stride, int32_t base_capacity,
+                        double floor_ratio, int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens,
+                        int32_t* cu_klen, int32_t* cu_headlens, int32_t* host_mirror, int32_t host_seq, void* ws, size_t ws_bytes,
+                        pkv_stream_t stream) {
+  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (!scores || !head_capacity || !ws) return PKV_ERR_NULL;
+  if ((head_lens == nullptr) != (cu_klen == nullptr)) return PKV_ERR_NULL;
+  if (H < 1 || H > 256 || L < 1 || base_capacity < 1 || base_capacity > L || scores_stride < L) return PKV_ERR_SHAPE;
+  if (L > 65536) return PKV_ERR_UNSUPPORTED;          // a row lives in the registers of one 1024-thread workgroup
+  if (ws_bytes < 1024 + (size_t)2 * H * 256 * 4) return PKV_ERR_WORKSPACE;
+  BudgetParams bp;
+  bp.sorted_val = nullptr; bp.sorted_idx = nullptr; bp.idx_stride = 0; bp.scores = scores; bp.scores_stride = scores_stride;
+  bp.Lrow = L; bp.H = H; bp.L = L; bp.base = base_capacity;
+  bp.one_minus_floor = (float)(1.0 - floor_ratio);
+  bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
+  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr; bp.unsorted = 1;
+  bp.window = window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
+  bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.adaptive_out = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(dtype, bp, st);
@@ -616,7 +640,7 @@ int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t M, const
   bp.sorted_val = nullptr; bp.sorted_idx = top_idx; bp.idx_stride = idx_stride; bp.scores = scores; bp.scores_stride = scores_stride;
   bp.Lrow = L; bp.H = H; bp.L = M; bp.base = base_capacity;
   bp.one_minus_floor = 1.0f; bp.floor_capacity = 0;
-  bp.normalize = normalize; bp.head_capacity = nullptr; bp.ws = ws; bp.list_ws = nullptr;
+  bp.normalize = normalize; bp.head_capacity = nullptr; bp.ws = ws; bp.list_ws = nullptr; bp.unsorted = 0;
   bp.window = 0; bp.head_lens_out = nullptr; bp.cu_klen_out = nullptr; bp.cu_headlens_out = nullptr;
   bp.host_mirror = nullptr; bp.host_seq = 0; bp.adaptive_out = lists_out;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -661,7 +685,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   bp.Lrow = L; bp.H = H; bp.L = M; bp.base = base_capacity;
   bp.one_minus_floor = (float)(1.0 - floor_ratio);
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
-  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = w + W.off_ada; bp.list_ws = w + W.off_ada_list;
+  bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = w + W.off_ada; bp.list_ws = w + W.off_ada_list; bp.unsorted = 0;
   bp.window = d->window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
   bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.adaptive_out = nullptr;
   ProfScope ps(PKV_K_BUDGET, st);

@@ -110,7 +110,7 @@ constexpr int F32_SPAN = 1024, F32_OUT = F32_SPAN - 16;
 
 __global__ __launch_bounds__(256) void finalize_f32_kernel(FinalizeParams p) {
   __shared__ __attribute__((aligned(16))) float sc[F32_SPAN];
-  __shared__ float rowM[64], rowS[64];
+  __shared__ float rowM[128], rowS[128];
   const int tid = threadIdx.x, bh = blockIdx.y;
   const int w = p.w, L = p.S - w;
   const int64_t rowbase = (int64_t)bh * w;

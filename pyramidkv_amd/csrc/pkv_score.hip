@@ -183,8 +183,8 @@ constexpr int FN_OUT = FN_SPAN - 16;       // positions written per workgroup
 template <typename T>
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   __shared__ __attribute__((aligned(16))) uint16_t sc[FN_SPAN];
-  __shared__ float rowM[64];
-  __shared__ float rowS[64];
+  __shared__ float rowM[128];           // window <= 128 (check_desc)
+  __shared__ float rowS[128];
 
   const int tid = threadIdx.x;
   const int bh = blockIdx.y;

@@ -157,13 +157,18 @@ def hip_head_sharded_adakv(num_heads_total: int, window_size: int, kernel_size: 
     all-gather of those lists -> the budget of all heads on every rank (normalisation already applied) -> flat gather of
     the local heads."""
     from . import ops, config as _cfg
+    from .pyramidkv_utils import _ADA_TOPM_MAX
     base = max_capacity_prompt - window_size
 
     def score_sort(q, k):
         s = ops.score_window(q, k, window_size, pooling, kernel_size, reduce="mean", scale_mode=_cfg.scale_mode,
                              kv_group=q.shape[1] // k.shape[1])[0]
         M = min(s.shape[-1], num_heads_total * base)
-        top_idx = ops.topk(s, M)
+        if M <= _ADA_TOPM_MAX:
+            top_idx = ops.topk(s, M)
+        else:                      # the single-GPU rule (pyramidkv_utils._ADA_TOPM_MAX): long lists come from the complete sort
+            top_idx, _ = ops.sort_rows(s, want_values=False)
+            top_idx = top_idx[:, :M].contiguous()
         return top_idx, ops.ada_adaptive_lists(s, top_idx, base, bool(normalize))
 
     def budget(all_lists):

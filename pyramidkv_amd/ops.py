@@ -118,8 +118,10 @@ def score_h2o(q, k, window: int, scale_mode: str = "div", kv_group: int = 1) -> 
     return out[..., :L]
 
 
-def topk(scores: torch.Tensor, k: int) -> torch.Tensor:
-    """pyramidkv_utils.py:334.  scores [..., L] (16-bit) -> int32 [..., k], (value desc, index asc)."""
+def topk(scores: torch.Tensor, k: int, k_per_row: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pyramidkv_utils.py:334.  scores [..., L] (16-bit) -> int32 [..., k], (value desc, index asc).  ``k_per_row`` (device
+    int32, one entry per row, each <= k): row r gets only its first k_per_row[r] entries (the rest of the row is unspecified) -
+    the per-head capacities of Ada-SnapKV / HeadKV."""
     _require_gpu(scores)
     if scores.stride(-1) != 1:
         scores = scores.contiguous()
@@ -137,12 +139,13 @@ def topk(scores: torch.Tensor, k: int) -> torch.Tensor:
     out = torch.empty(*lead, k, dtype=torch.int32, device=scores.device)
     with torch.cuda.device(scores.device):
         nb = N.lib.pkv_topk_workspace_bytes(rows, L, k)          # > 0 only for rows beyond one workgroup's LDS
+        kpr = k_per_row.data_ptr() if k_per_row is not None else None
         if nb:
             ws = workspace(nb, scores.device)
-            N.check(N.lib.pkv_topk_ws(N.dtype_code(scores.dtype), rows, L, k, scores.data_ptr(), stride, None,
+            N.check(N.lib.pkv_topk_ws(N.dtype_code(scores.dtype), rows, L, k, scores.data_ptr(), stride, kpr,
                                       out.data_ptr(), k, ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_topk_ws")
         else:
-            N.check(N.lib.pkv_topk(N.dtype_code(scores.dtype), rows, L, k, scores.data_ptr(), stride, None,
+            N.check(N.lib.pkv_topk(N.dtype_code(scores.dtype), rows, L, k, scores.data_ptr(), stride, kpr,
                                    out.data_ptr(), k, N.stream_ptr()), "pkv_topk")
     return out
 
@@ -288,6 +291,27 @@ def ada_budget_topm(scores: torch.Tensor, top_idx: torch.Tensor, base_capacity: 
                                           cu.data_ptr() if window is not None else None,
                                           ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_ada_budget_topm")
     return (cap, head_lens, cu) if window is not None else cap
+
+
+def ada_budget_rows(scores: torch.Tensor, base_capacity: int, floor_ratio: float, normalize: bool, window: int,
+                    host_mirror: Optional[torch.Tensor] = None, host_seq: int = 0):
+    """pyramidkv_utils.py:706-719 from the un-sorted rows alone (pkv_ada_budget_rows): scores [H,L] -> (head_capacity,
+    head_lens, cu_klen, cu_headlens), device int32.  No sort and no top-M list: selections and counts over the whole row."""
+    _require_gpu(scores)
+    assert scores.dim() == 2 and scores.stride(-1) == 1
+    H, L = scores.shape
+    dev = scores.device
+    meta = torch.empty(4 * H + 1, dtype=torch.int32, device=dev)
+    cap, head_lens, cu, cuh = meta[:H], meta[H:2 * H], meta[2 * H:3 * H + 1], meta[3 * H + 1:]
+    nb = 1024 + 2 * H * 256 * 4
+    with torch.cuda.device(dev):
+        ws = workspace(nb, dev)
+        N.check(N.lib.pkv_ada_budget_rows(N.dtype_code(scores.dtype), H, L, scores.data_ptr(), scores.stride(0), base_capacity,
+                                          float(floor_ratio), 1 if normalize else 0, int(window), cap.data_ptr(),
+                                          head_lens.data_ptr(), cu.data_ptr(), cuh.data_ptr(),
+                                          host_mirror.data_ptr() if host_mirror is not None else None, int(host_seq),
+                                          ws.data_ptr(), ws.numel(), N.stream_ptr()), "pkv_ada_budget_rows")
+    return cap, head_lens, cu, cuh
 
 
 def ada_adaptive_lists(scores: torch.Tensor, top_idx: torch.Tensor, base_capacity: int, normalize: bool) -> torch.Tensor:

@@ -442,8 +442,29 @@ class AdaKVCluster(_FlatPolicy):
             bound = num_heads * self.base_capacity + num_heads + num_heads * self.window_size
             return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, meta=(head_lens, cu, cuh),
                                             rows_bound=bound, mirror=mirror)
-        attn_score = self._scores(key_states, query_states)                          # [1,H,L]
-        sorted_idx, sorted_val = ops.sort_rows(attn_score[0])                        # :706
+        # H*base > 4096 (budget 2048: M is the whole row, a top-M list would be a full sort).  What :706-719 consume of the
+        # order are selections and counts: the budgets come from histograms over the un-sorted rows (pkv_ada_budget_rows),
+        # then every head's first cap_h entries of the canonical order from one top-k launch with per-head k.  Rows or
+        # capacities beyond one top-k workgroup keep the complete sort.
+        attn_score = self._scores(key_states, query_states)[0]                       # [H, L]   :647-672
+        if L <= 65536:
+            mirror = None
+            if _cfg.host_poll:
+                mirror = getattr(self, "_mirror", None)
+                if mirror is None or mirror.H != num_heads:
+                    mirror = self._mirror = _HostMirror(num_heads)
+            cap, head_lens, cu, cuh = ops.ada_budget_rows(
+                attn_score, self.base_capacity, self.floor_ratio, bool(self.normalize), self.window_size,   # :709-719, :682-691
+                host_mirror=mirror.t if mirror is not None else None, host_seq=mirror.next_seq() if mirror is not None else 0)
+            caps = mirror.wait(key_states.device) if mirror is not None else _read_back(cap)   # the one host sync (:718)
+            try:
+                top_idx = ops.topk(attn_score, max(1, max(caps)), k_per_row=cap)
+            except ValueError:                                                       # beyond one workgroup's LDS
+                top_idx = None
+            if top_idx is not None:
+                return self._flat_from_capacity(key_states, value_states, top_idx, cap, num_heads, caps_host=caps,
+                                                meta=(head_lens, cu, cuh))
+        sorted_idx, sorted_val = ops.sort_rows(attn_score)                           # :706
         cap = ops.ada_budget(sorted_val, self.base_capacity, self.floor_ratio, bool(self.normalize))  # :709-719
         return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads)
 
@@ -483,8 +504,11 @@ class HeadKVCluster(_FlatPolicy):
                 given_capacity=cap, scale_mode=_cfg.scale_mode, kv_group=_unexpanded_group(key_states, query_states))
             return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, caps_host=caps,
                                             meta=(head_lens, cu, cuh))
-        attn_score = self._scores(key_states, query_states)
-        sorted_idx, _ = ops.sort_rows(attn_score[0], want_values=False)              # :840
+        attn_score = self._scores(key_states, query_states)[0]
+        try:                                                                         # per-head top-cap_h instead of the sort of :840
+            sorted_idx = ops.topk(attn_score, max(caps), k_per_row=cap)
+        except ValueError:                                                           # beyond one top-k workgroup's LDS
+            sorted_idx, _ = ops.sort_rows(attn_score, want_values=False)             # :840
         return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, caps_host=caps)
 
 

@@ -254,6 +254,35 @@ def test_window_scores_wide_gqa_group_and_window(P):
     assert mx <= 1 and frac <= SCORE_MISMATCH_FRAC, (frac, mx)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("S,w,g,pool,ks,red", [(1500, 128, 1, "avgpool", 5, "sum"), (700, 96, 2, "maxpool", 7, "mean"),
+                                               (4100, 128, 2, None, 1, "sum"), (130, 128, 1, "maxpool", 3, "sum")])
+def test_window_scores_windows_up_to_128(P, dt, S, w, g, pool, ks, red):
+    """Observation windows beyond 64 rows (the reference takes any window_size, :286/:317; its constructor default is 64):
+    scores vs the oracle for windows 96 and 128, with and without un-expanded GQA K (kv_group * window <= 256 columns), a
+    prompt barely longer than its window, every dtype; then SnapKV end to end (indices == canonical top-k of the scores)."""
+    Hkv = 2
+    q, k, v = make_qkv(1, Hkv * g, S, 128, dt, "gauss", 23)
+    k, v = k[:, ::g].contiguous(), v[:, ::g].contiguous()
+    kx = k[:, :, None].expand(1, Hkv, g, S, 128).reshape(1, Hkv * g, S, 128)
+    vx = v[:, :, None].expand(1, Hkv, g, S, 128).reshape(1, Hkv * g, S, 128)
+    want = O.pool_scores(O.window_scores(q, kx, w, red), pool, ks)
+    got = P.ops.score_window(q.to(DEV), k.to(DEV), w, pool, ks, red, kv_group=g).cpu()
+    if dt == "fp32":
+        assert torch.allclose(got, want, rtol=2e-5, atol=1e-9)
+    else:
+        frac, mx = score_diff(got, want)
+        assert mx <= 1 and frac <= SCORE_MISMATCH_FRAC, (frac, mx)
+    if pool is not None and S - w > 40:
+        kk = min(40, S - w - 1)
+        cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=kk + w, kernel_size=ks, pooling=pool)
+        kc, vc = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV), None, g)
+        sg = P.ops.score_window(q.to(DEV), k.to(DEV), w, pool, ks, "sum", kv_group=g).cpu()
+        idx = O.topk_canonical(sg, kk)
+        kr, vr = O.gather_compact(kx, vx, idx, w)
+        assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+
+
 def test_window_scores_32k(P):
     q, k, _ = make_qkv(1, 4, 32768, 128, "bf16", "gauss", 1234)
     want = O.pool_scores(O.window_scores(q, k, 8), "maxpool", 7)
@@ -465,6 +494,72 @@ def test_ada_budget_and_flat_gather_exact_given_scores(P, dt, pool, ks, floor, n
     kr, vr, lens = O._flat_gather(k, v, per_head, w)
     assert hl.cpu().tolist() == lens
     assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_ada_budget_rows_equals_sorted_path_and_oracle(P, dt):
+    """pkv_ada_budget_rows (histograms over the UN-SORTED rows) == pkv_ada_budget on the completely sorted rows == the oracle's
+    :706-719, over random geometries incl. heavy ties (rounded scores, plateaus), floor 0 / 1, normalize on / off, and a
+    budget that takes more than the row of one head can give."""
+    rng = np.random.default_rng(5)
+    for case in range(20):
+        H = int(rng.choice([1, 3, 8, 32]))
+        L = int(rng.integers(50, 9000))
+        base = int(rng.integers(1, L + 1))
+        floor = float(rng.choice([0.0, 0.2, 0.5, 1.0]))
+        norm = bool(rng.integers(0, 2))
+        g = torch.Generator().manual_seed(700 + case)
+        s = torch.rand(H, L, generator=g) ** 4
+        if case % 3 == 0:
+            s = (s * 16).round() / 16                      # a handful of distinct values: ties everywhere
+        if case % 4 == 1:
+            s[:, : L // 2] = s[:, :1]                      # half of every row is one plateau
+        s = s.to(torch.bfloat16 if dt == "bf16" else torch.float16)
+        sd = s.to(DEV)
+        _, cap_ref = O.adakv_head_capacity(s[None], base, floor, norm, "canonical")
+        _, sv = P.ops.sort_rows(sd)
+        cap_sorted = P.ops.ada_budget(sv, base, floor, norm)
+        cap_rows, head_lens, cu, cuh = P.ops.ada_budget_rows(sd, base, floor, norm, 8)
+        assert cap_rows.cpu().tolist() == cap_sorted.cpu().tolist() == cap_ref[0].tolist(), (case, H, L, base, floor, norm)
+        lens = [c + 8 for c in cap_rows.cpu().tolist()]
+        assert head_lens.cpu().tolist() == lens and cu.cpu().tolist() == [0] + np.cumsum(lens).tolist()
+        assert cuh.cpu().tolist() == np.cumsum(lens).tolist()
+        # every head's first cap_h entries of the canonical order from ONE top-k launch with per-head k
+        kmax = max(1, int(cap_rows.max()))
+        if kmax <= 4096:
+            ti = P.ops.topk(sd, kmax, k_per_row=cap_rows).cpu().long()
+            want = torch.sort(s, dim=-1, descending=True, stable=True).indices
+            for h in range(H):
+                c = int(cap_rows[h])
+                assert torch.equal(ti[h, :c], want[h, :c]), (case, h)
+
+
+def test_adakv_large_budget_without_the_sort(P):
+    """H * base > 4096: AdaKVCluster takes its budgets from pkv_ada_budget_rows and its index lists from a per-head top-k
+    (no complete sort): head budgets, metadata and the flat K/V bit-identical to the oracle.  HeadKV with capacities above
+    4096 takes the same per-head top-k."""
+    H, S, w, cap = 8, 8192, 8, 1032                      # H * base = 8192
+    q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 64)
+    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2,
+                        normalize=True, layer_idx=0, num_hidden_layers=32)
+    kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
+    sg = P.ops.score_window(q.to(DEV), k.to(DEV), w, "maxpool", 7, "mean").cpu()[0]
+    sidx, caps = O.adakv_head_capacity(sg[None], cap - w, 0.2, True)
+    caps = caps[0].tolist()
+    assert cl.head_lens.cpu().tolist() == [c + w for c in caps]
+    assert int(cl.klen_sum) == sum(caps) + H * w == kf.shape[0] and cl.max_seqlen_k == max(caps) + w
+    kr, vr, _ = O._flat_gather(k, v, [sidx[0, h, :caps[h]] for h in range(H)], w)
+    assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr)
+    kr2, vr2, meta = O.adakv_update_kv(k, q, v, w, cap, 7, "maxpool", 0.2, True)      # end to end (the oracle's own scores)
+    _report("adakv_large_budget/S8192cap1032", dict(head_lens_identical=cl.head_lens.cpu().tolist() == meta.head_lens.tolist(),
+                                                   kv_identical=bool(torch.equal(kf.cpu(), kr2) and torch.equal(vf.cpu(), vr2))))
+    hc = [[5000, 17, 4097, 8000, 1, 6000, 300, 4500]]
+    hk = P.HeadKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, layer_idx=0,
+                         num_hidden_layers=32, head_capacity=hc)
+    kf, vf = hk.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
+    order = torch.sort(sg, dim=-1, descending=True, stable=True).indices
+    kr, vr, lens = O._flat_gather(k, v, [order[h, :hc[0][h]] for h in range(H)], w)
+    assert hk.head_lens.cpu().tolist() == lens and torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr)
 
 
 def test_adakv_cluster_metadata_and_consistency(P):
