@@ -53,8 +53,8 @@ enum pkv_scale { PKV_SCALE_DIV = 0, PKV_SCALE_RCP = 1 };
 
 typedef struct pkv_desc {
   int32_t dtype;        /* pkv_dtype of q,k,v and of every score buffer */
-  int32_t B, H, S, D;   /* H = number of query heads; D = 128 (all entry points) or 64 / 256 (not pkv_score_h2o,
-                           pkv_compress_h2o, pkv_merge_compact: PKV_ERR_UNSUPPORTED) */
+  int32_t B, H, S, D;   /* H = number of query heads; D = 128 (all entry points) or 64 / 256 (not
+                           pkv_merge_compact: PKV_ERR_UNSUPPORTED) */
   int32_t kv_group;     /* 1: k,v have H heads (post-repeat_kv, the reference contract).
                            g>1: k,v have H/g heads (un-expanded GQA); head h reads kv head h/g */
   int64_t q_stride[3];  /* element strides of q for b,h,s */

@@ -94,7 +94,7 @@ struct ProfScope {
 int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true, bool f32_ok = false) {
   if (!d) return PKV_ERR_NULL;
   if (d->dtype != PKV_BF16 && d->dtype != PKV_F16 && d->dtype != PKV_F32) return PKV_ERR_DTYPE;
-  if (d->D != 64 && d->D != 128 && d->D != 256) return PKV_ERR_SHAPE;      // H2O and the merge: 128 only (checked there)
+  if (d->D != 64 && d->D != 128 && d->D != 256) return PKV_ERR_SHAPE;      // the merge: 128 only (checked there)
   if (d->dtype == PKV_F32 && (!f32_ok || d->D == 256)) return PKV_ERR_UNSUPPORTED;
   if (d->B < 1 || d->H < 1 || d->S < 2) return PKV_ERR_SHAPE;
   if (d->kv_group < 1 || d->H % d->kv_group) return PKV_ERR_SHAPE;
@@ -236,7 +236,7 @@ int do_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores, 
   hp.q = q; hp.k = k;
   hp.rowstat = reinterpret_cast<float2*>(ws + L.off_rowstat);
   hp.scores = scores; hp.scores_stride = stride;
-  hp.B = d->B; hp.H = d->H; hp.S = d->S; hp.w = d->window; hp.G = d->kv_group;
+  hp.B = d->B; hp.H = d->H; hp.S = d->S; hp.w = d->window; hp.G = d->kv_group; hp.D = d->D;
   hp.qs_b = d->q_stride[0]; hp.qs_h = d->q_stride[1]; hp.qs_s = d->q_stride[2];
   hp.ks_b = d->k_stride[0]; hp.ks_h = d->k_stride[1]; hp.ks_s = d->k_stride[2];
   hp.scale_mode = d->scale_mode;
@@ -353,7 +353,6 @@ int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, c
   char* w = static_cast<char*>(ws);
   void* scores = w + L.off_scores;
   const bool cm = !h2o && d->dtype != PKV_F32 && env_int("PKV_TOPK_CMAX", 1) != 0;   // chunk maxima feed the top-k prefilter
-  if (h2o && d->D != 128) return PKV_ERR_UNSUPPORTED;
   rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
   int32_t* idx = idx_out ? idx_out : reinterpret_cast<int32_t*>(w + L.off_idx);
@@ -413,7 +412,6 @@ int pkv_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores_
   int rc = check_desc(d, false);
   if (rc) return rc;
   if (!q || !k || !scores_out || !ws) return PKV_ERR_NULL;
-  if (d->D != 128) return PKV_ERR_UNSUPPORTED;
   if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
   WsLayout L = ws_layout(d);
   if (ws_bytes < L.total) return PKV_ERR_WORKSPACE;
@@ -483,7 +481,6 @@ int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int
   if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
   WsLayout L = ws_layout(d);
   if (ws_bytes < (h2o ? L.total : L.off_rowstat)) return PKV_ERR_WORKSPACE;
-  if (h2o && d->D != 128) return PKV_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* w = static_cast<char*>(ws);
   void* scores = w + L.off_scores;

@@ -99,8 +99,9 @@ constexpr int HT = 64;                 // streamed rows per LDS tile
 constexpr int HR = 64;                 // resident rows per wave
 constexpr int HWG = 4 * HR;            // resident rows per workgroup
 
-struct Stager {                        // one thread's share of a 64 x 256 B tile: 4 x 16 B
-  u32x4 v[4];
+// KS = head_dim / 32 MFMA k-steps (2, 4, 8 for head sizes 64, 128, 256).  A row is CPR = 4 * KS chunks of 16 B.
+template <int KS> struct Stager {      // one thread's share of a 64-row tile: 64 * CPR / 256 = KS chunks of 16 B
+  u32x4 v[KS];
 };
 
 // The streamed matrix of one head as a raw buffer.  Per thread one byte offset (row tid/16, chunk tid%16), computed
@@ -112,48 +113,59 @@ struct TileStream {
   int nrows;
   uint32_t voff;                       // this thread's byte offset inside a tile
 };
+template <int KS>
 __device__ __forceinline__ TileStream make_stream(const uint16_t* base, int64_t stride, int nrows, int tid) {
+  constexpr int CPR = 4 * KS;
   TileStream s;
   s.base = base; s.stride_b = stride * 2; s.nrows = nrows;
-  s.voff = (uint32_t)(tid >> 4) * (uint32_t)s.stride_b + (uint32_t)(tid & 15) * 16u;
+  s.voff = (uint32_t)(tid / CPR) * (uint32_t)s.stride_b + (uint32_t)(tid % CPR) * 16u;
   return s;
 }
-__device__ __forceinline__ void stage_load(Stager& st, const TileStream& s, int row0) {
+template <int KS>
+__device__ __forceinline__ void stage_load(Stager<KS>& st, const TileStream& s, int row0) {
+  constexpr int CPR = 4 * KS, RPP = 256 / CPR;                             // rows covered by one pass of the 256 threads
   const int left = s.nrows - row0;                                          // rows still inside the matrix (scalar)
-  const int64_t ext = left > 0 ? (int64_t)(left - 1) * s.stride_b + 256 : 0;
+  const int64_t ext = left > 0 ? (int64_t)(left - 1) * s.stride_b + CPR * 16 : 0;
   const uint32_t extent = ext > 0xffffffffll ? 0xffffffffu : (uint32_t)ext;
   const char* tile = reinterpret_cast<const char*>(s.base) + (left > 0 ? (int64_t)row0 * s.stride_b : 0);
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tile), 0, extent, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    st.v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, s.voff, (uint32_t)(16 * i) * (uint32_t)s.stride_b, 0));
+  for (int i = 0; i < KS; ++i)
+    st.v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, s.voff, (uint32_t)(RPP * i) * (uint32_t)s.stride_b, 0));
 }
-__device__ __forceinline__ void stage_store(const Stager& st, u32x4* tile, int tid) {
-  const int c = tid & 15, r0 = tid >> 4;
+// chunk c of row r sits at chunk c ^ (r & SW): the fragment read below (16 rows x one chunk per 4-lane group) is then
+// bank-conflict free; SW = 15 for 16 and 32 chunks per row, 7 for 8
+template <int KS>
+__device__ __forceinline__ void stage_store(const Stager<KS>& st, u32x4* tile, int tid) {
+  constexpr int CPR = 4 * KS, RPP = 256 / CPR, SW = CPR >= 16 ? 15 : CPR - 1;
+  const int c = tid % CPR, r0 = tid / CPR;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + 16 * i;
-    tile[r * 16 + (c ^ (r & 15))] = st.v[i];
+  for (int i = 0; i < KS; ++i) {
+    const int r = r0 + RPP * i;
+    tile[r * CPR + (c ^ (r & SW))] = st.v[i];
   }
 }
-__device__ __forceinline__ void read_frags(u32x4 (&f)[4], const u32x4* tile, int sub, int li, int lg) {
+template <int KS>
+__device__ __forceinline__ void read_frags(u32x4 (&f)[KS], const u32x4* tile, int sub, int li, int lg) {
+  constexpr int CPR = 4 * KS, SW = CPR >= 16 ? 15 : CPR - 1;
   const int r = sub * 16 + li;
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) f[kk] = tile[r * 16 + ((kk * 4 + lg) ^ li)];
+  for (int kk = 0; kk < KS; ++kk) f[kk] = tile[r * CPR + ((kk * 4 + lg) ^ (li & SW))];
 }
-__device__ __forceinline__ void load_frags(u32x4 (&f)[4], const uint16_t* base, int64_t row, int64_t stride, int lg) {
+template <int KS>
+__device__ __forceinline__ void load_frags(u32x4 (&f)[KS], const uint16_t* base, int64_t row, int64_t stride, int lg) {
   const uint16_t* r = base + row * stride + lg * 8;
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const u32x4*>(r + kk * 32);
+  for (int kk = 0; kk < KS; ++kk) f[kk] = *reinterpret_cast<const u32x4*>(r + kk * 32);
 }
 // the 16 MFMAs of one 16-row sub-tile (fragments f, the A operand) against the wave's 64 resident rows (B): four
 // independent accumulators back to back, no dependent-MFMA stall.  D[streamed row][resident row].
-template <typename T>
-__device__ __forceinline__ void mm16(f32x4 (&acc)[4], const u32x4 (&f)[4], const u32x4 (&res)[4][4]) {
+template <typename T, int KS>
+__device__ __forceinline__ void mm16(f32x4 (&acc)[4], const u32x4 (&f)[KS], const u32x4 (&res)[4][KS]) {
 #pragma unroll
   for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
+  for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = Mfma2<T>::run(f[kk], res[n][kk], acc[n]);
 }
@@ -161,9 +173,10 @@ __device__ __forceinline__ void mm16(f32x4 (&acc)[4], const u32x4 (&f)[4], const
 // Pass 1: per query row, max and sum of exp over all keys.  Resident = 256 query rows, streamed = K.
 // Per-lane online statistics (lane's column = one query, 4 keys per 16-key subtile); the running maximum
 // is only rescaled when some lane of the wave actually found a larger logit (wave-uniform branch).
-template <typename T>
+template <typename T, int KS>
 __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
-  __shared__ __attribute__((aligned(16))) u32x4 tiles[2][HT * 16];
+  extern __shared__ __attribute__((aligned(16))) unsigned char h2o_smem[];               // 2 tiles (64 KB at head size 256)
+  u32x4 (*tiles)[HT * 4 * KS] = reinterpret_cast<u32x4 (*)[HT * 4 * KS]>(h2o_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y;
@@ -172,22 +185,22 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b + (int64_t)h * p.qs_h;
   const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const int q0 = blockIdx.x * HWG + wave * HR;
-  u32x4 qf[4][4];
+  u32x4 qf[4][KS];
   int qi[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
     qi[n] = q0 + n * 16 + li;
-    load_frags(qf[n], qb, qi[n] < S ? qi[n] : S - 1, p.qs_s, lg);
+    load_frags<KS>(qf[n], qb, qi[n] < S ? qi[n] : S - 1, p.qs_s, lg);
   }
   const float L2E = 1.44269504088896340736f;
   float m[4], mL[4], Z[4];          // running max, -max*log2e, running sum of exp
 #pragma unroll
   for (int n = 0; n < 4; ++n) { m[n] = -INFINITY; mL[n] = 0.f; Z[n] = 0.f; }
 
-  const TileStream ks = make_stream(kb, p.ks_s, S, tid);
-  Stager stg;
-  stage_load(stg, ks, 0);
-  stage_store(stg, tiles[0], tid);
+  const TileStream ks = make_stream<KS>(kb, p.ks_s, S, tid);
+  Stager<KS> stg;
+  stage_load<KS>(stg, ks, 0);
+  stage_store<KS>(stg, tiles[0], tid);
   __syncthreads();
   const int ntiles = (S + HT - 1) / HT;
   // tiles that touch the end of the row or the masked corner run the EDGE instance of the body; all others carry no
@@ -196,14 +209,14 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
     constexpr bool edge = decltype(edge_tag)::value;
     const int s_tile = t * HT;
     const u32x4* cur = tiles[t & 1];
-    stage_load(stg, ks, s_tile + HT);                                         // in flight during the compute below; past the end: zeros
+    stage_load<KS>(stg, ks, s_tile + HT);                                     // in flight during the compute below; past the end: zeros
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      u32x4 kf[4];
-      read_frags(kf, cur, sub, li, lg);
+      u32x4 kf[KS];
+      read_frags<KS>(kf, cur, sub, li, lg);
       const int s0 = s_tile + sub * 16;
       f32x4 accs[4];
-      mm16<T>(accs, kf, qf);                                                  // D[key][query]
+      mm16<T, KS>(accs, kf, qf);                                              // D[key][query]
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         float x[4];
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
                 (__builtin_amdgcn_exp2f(y[2]) + __builtin_amdgcn_exp2f(y[3]));
       }
     }
-    stage_store(stg, tiles[(t + 1) & 1], tid);                                // buffer last read in iteration t-1
+    stage_store<KS>(stg, tiles[(t + 1) & 1], tid);                            // buffer last read in iteration t-1
     __syncthreads();
   };
   const int t_plain = (L < S ? L : S) / HT;                                   // tiles [0, t_plain) end at or before L
@@ -258,10 +271,11 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
 
 // Pass 2: per key column, sum over all query rows of round(exp(x - m) / Z).  Resident = 256 key columns,
 // streamed = Q (+ the 64 row constants c_row of the tile).  No branch in the loop.
-template <typename T>
+template <typename T, int KS>
 __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
-  __shared__ __attribute__((aligned(16))) u32x4 tiles[2][HT * 16];
-  __shared__ __attribute__((aligned(16))) float stats[2][HT];             // c_row of the 64 streamed query rows
+  extern __shared__ __attribute__((aligned(16))) unsigned char h2o_smem[];               // 2 tiles + 2 x 64 row constants
+  u32x4 (*tiles)[HT * 4 * KS] = reinterpret_cast<u32x4 (*)[HT * 4 * KS]>(h2o_smem);
+  float (*stats)[HT] = reinterpret_cast<float (*)[HT]>(h2o_smem + (size_t)2 * HT * 4 * KS * 16);   // c_row of the 64 streamed query rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y;
@@ -272,12 +286,12 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
   const float2* rs = p.rowstat + (int64_t)bh * S;
   const int k0 = blockIdx.x * HWG + wave * HR;
 
-  u32x4 kf[4][4];
+  u32x4 kf[4][KS];
   int kj[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
     kj[n] = k0 + n * 16 + li;
-    load_frags(kf[n], kb, kj[n] < S ? kj[n] : S - 1, p.ks_s, lg);
+    load_frags<KS>(kf[n], kb, kj[n] < S ? kj[n] : S - 1, p.ks_s, lg);
   }
   // matrix-pipe column sums (see the header): every row of cacc[n] holds the sums of key columns kj[n]
   f32x4 cacc[4];
@@ -291,26 +305,26 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
     return i < S ? c : -INFINITY;
   };
 
-  const TileStream qs = make_stream(qb, p.qs_s, S, tid);
-  Stager stg;
-  stage_load(stg, qs, 0);
+  const TileStream qs = make_stream<KS>(qb, p.qs_s, S, tid);
+  Stager<KS> stg;
+  stage_load<KS>(stg, qs, 0);
   float sreg = row_const(lane);                                // all four waves carry the same 64 constants: no divergent branch
-  stage_store(stg, tiles[0], tid);
+  stage_store<KS>(stg, tiles[0], tid);
   stats[0][lane] = sreg;
   __syncthreads();
   const int ntiles = (S + HT - 1) / HT;
   for (int t = 0; t < ntiles; ++t) {
     const u32x4* cur = tiles[t & 1];
     const float* cst = stats[t & 1];
-    stage_load(stg, qs, (t + 1) * HT);                         // past the end: zeros (and c_row = -inf)
+    stage_load<KS>(stg, qs, (t + 1) * HT);                     // past the end: zeros (and c_row = -inf)
     sreg = row_const((t + 1) * HT + lane);
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      u32x4 qf[4];
-      read_frags(qf, cur, sub, li, lg);
+      u32x4 qf[KS];
+      read_frags<KS>(qf, cur, sub, li, lg);
       const f32x4 st = *reinterpret_cast<const f32x4*>(cst + sub * 16 + lg * 4);
       f32x4 accs[4];
-      mm16<T>(accs, qf, kf);                                   // D[query][key]
+      mm16<T, KS>(accs, qf, kf);                               // D[query][key]
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         float x[4], e[4];
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
         }
       }
     }
-    stage_store(stg, tiles[(t + 1) & 1], tid);
+    stage_store<KS>(stg, tiles[(t + 1) & 1], tid);
     stats[(t + 1) & 1][lane] = sreg;
     __syncthreads();
   }
@@ -336,10 +350,6 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
     if (lg == 0 && kj[n] < L) out[kj[n]] = Elem<T>::from_f32(cacc[n][0]);
 }
 
-template __global__ void h2o_stats_kernel<BF16>(H2OParams);
-template __global__ void h2o_stats_kernel<F16>(H2OParams);
-template __global__ void h2o_colsum_kernel<BF16>(H2OParams);
-template __global__ void h2o_colsum_kernel<F16>(H2OParams);
 
 // raw-buffer tile loads carry 32-bit offsets: 64 rows of the streamed matrix must span less than 4 GB
 static bool strides_ok(const H2OParams& p) {
@@ -349,8 +359,19 @@ static bool strides_ok(const H2OParams& p) {
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
   if (!strides_ok(p)) return hipErrorInvalidValue;
   dim3 grid((p.S + HWG - 1) / HWG, p.B * p.H);
-  if (dtype == 0) hipLaunchKernelGGL(h2o_stats_kernel<BF16>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(h2o_stats_kernel<F16>, grid, dim3(256), 0, st, p);
+#define PKV_H2O_S(TT, KS)                                                                                             \
+  do {                                                                                                                \
+    const size_t lds_ = (size_t)2 * HT * 4 * KS * 16;                                                                 \
+    if (lds_ >= 64 * 1024) {                                                                                          \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(h2o_stats_kernel<TT, KS>),                    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                    \
+      if (e_ != hipSuccess) return e_;                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((h2o_stats_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                     \
+  } while (0)
+  if (dtype == 0) { if (p.D == 64) PKV_H2O_S(BF16, 2); else if (p.D == 256) PKV_H2O_S(BF16, 8); else PKV_H2O_S(BF16, 4); }
+  else { if (p.D == 64) PKV_H2O_S(F16, 2); else if (p.D == 256) PKV_H2O_S(F16, 8); else PKV_H2O_S(F16, 4); }
+#undef PKV_H2O_S
   return hipGetLastError();
 }
 
@@ -358,8 +379,19 @@ hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st) {
   if (!strides_ok(p)) return hipErrorInvalidValue;
   const int L = p.S - p.w;
   dim3 grid((L + HWG - 1) / HWG, p.B * p.H);
-  if (dtype == 0) hipLaunchKernelGGL(h2o_colsum_kernel<BF16>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(h2o_colsum_kernel<F16>, grid, dim3(256), 0, st, p);
+#define PKV_H2O_C(TT, KS)                                                                                             \
+  do {                                                                                                                \
+    const size_t lds_ = (size_t)2 * HT * 4 * KS * 16 + 2 * HT * 4;                                                    \
+    if (lds_ >= 64 * 1024) {                                                                                          \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(h2o_colsum_kernel<TT, KS>),                   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                    \
+      if (e_ != hipSuccess) return e_;                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((h2o_colsum_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                    \
+  } while (0)
+  if (dtype == 0) { if (p.D == 64) PKV_H2O_C(BF16, 2); else if (p.D == 256) PKV_H2O_C(BF16, 8); else PKV_H2O_C(BF16, 4); }
+  else { if (p.D == 64) PKV_H2O_C(F16, 2); else if (p.D == 256) PKV_H2O_C(F16, 8); else PKV_H2O_C(F16, 4); }
+#undef PKV_H2O_C
   return hipGetLastError();
 }
 

@@ -178,6 +178,7 @@ struct H2OParams {
   void* scores;
   int64_t scores_stride;
   int B, H, S, w, G;
+  int D;              // head size: 64, 128 or 256
   int64_t qs_b, qs_h, qs_s;
   int64_t ks_b, ks_h, ks_s;
   int scale_mode;

@@ -392,7 +392,7 @@ def test_head_sizes_64_and_256_window_policies(P, D, dt):
     """The window policies, the gather and the flat var-len path at head sizes 64 and 256 (the reference is shape-generic,
     pyramidkv_utils.py:317; its supported model families use 128): scores within 1 ulp of the oracle, indices == canonical top-k
     of the kernel's own scores, K/V == exact gather incl. un-expanded GQA and strided views; Ada-SnapKV budgets and flat K/V
-    from the kernel's own scores == the oracle's arithmetic on them.  H2O and the merge are 128-only and say so."""
+    from the kernel's own scores == the oracle's arithmetic on them.  H2O runs at these head sizes too (round 3); the merge is 128-only and says so."""
     B, Hk, g, S, w, k = 2, 2, 2, 3001, 8, 77
     H = Hk * g
     q, kf, vf = make_qkv(B, H, S, D, dt, "gauss", 9500 + D)
@@ -435,8 +435,16 @@ def test_head_sizes_64_and_256_window_policies(P, D, dt):
     knew, _ = cache.update(nk.to(DEV), nk.to(DEV), 0, {"head_lens": cl.head_lens, "cu_klen": cl.cu_klen})
     want = O.update_flatten_view(kfl.cpu(), nk[0, :, 0], cl.head_lens.cpu(), cl.cu_klen.cpu())
     assert torch.equal(knew.cpu(), want)
-    with pytest.raises(ValueError):
-        P.ops.score_h2o(qd, kd, w, kv_group=g)
+    # H2O at this head size (round 3; k-steps = D / 32 like the window scores): scores vs the oracle, update_kv vs the
+    # canonical selection under the kernel's scores
+    from test_gpu_parity import H2O_MISMATCH_FRAC
+    sg = P.ops.score_h2o(qd, kd, w, kv_group=g).cpu()
+    want = O.h2o_scores(q, k_exp, w)
+    frac, mx = score_diff(sg, want)
+    assert mx <= 1 and frac <= H2O_MISMATCH_FRAC, (D, dt, frac, mx)
+    kc, vc = P.H2OKVCluster(window_size=w, max_capacity_prompt=64).update_kv(kd, qd, vd, None, g)
+    kr, vr = O.gather_compact(k_exp, v_exp, O.topk_canonical(sg, 64 - w), w)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
     with pytest.raises(ValueError):
         P.ops.merge_compact(k_exp.to(DEV), v_exp.to(DEV), idx[:, :, :10].contiguous(), w)
     with pytest.raises(ValueError):
