@@ -13,7 +13,7 @@ kinds = {}
 while time.time() - t0 < budget:
     pol = rng.choice(["snapkv", "pyramidkv", "h2o", "streamingllm", "adakv", "headkv", "merge", "f32"])
     S = int(rng.choice([rng.randint(70, 600), rng.randint(600, 9000), rng.choice([16384, 32768])])) if pol not in ("h2o",) else int(rng.randint(70, 3000))
-    w = int(rng.choice([8, 16, 32, 64]))
+    w = int(rng.choice([8, 16, 32, 64, 128]))
     G = int(rng.choice([1, 2, 4]))
     H = G * int(rng.randint(1, 5))
     B = 1 if pol in ("adakv", "headkv") else int(rng.randint(1, 3))
