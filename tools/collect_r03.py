@@ -34,7 +34,7 @@ def first_json_line(path):
 
 for name in ("bench.json", "sweep.json", "bw_probe.json", "parity_report.json", "policy_bench.json", "ada_bench.json", "topk_trace.json",
              "pytest.txt", "bench_rccl_n1.json", "bench_rccl_n1.log", "bench_n2_gloo_selflaunch.json", "bench_n2_gloo_selflaunch.log",
-             "bench_n2_nccl_one_gpu.log", "parity_sweep.json"):
+             "bench_n2_nccl_one_gpu.log", "parity_sweep.json", "soak.txt"):
     if os.path.exists(os.path.join(G, name)):
         shutil.copy(os.path.join(G, name), os.path.join(P, name))
     elif name == "parity_report.json" and os.path.exists(os.path.join(ROOT, "gpurun_out", name)):

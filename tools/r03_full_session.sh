@@ -39,4 +39,5 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIV
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_h2o_c -- python $R/tools/h2o_only.py 32768 > $O/pmc_h2o_c.log 2>&1
 fi
 cd $R
-tail -4 $O/pytest.txt 2>/dev/null; head -c 400 $O/bench.json; echo; tail -2 $O/bench.err; tail -1 $O/parity_sweep.log
+timeout 200 python tools/soak.py 60 > $O/soak.txt 2>&1; echo "soak exit $?" >> $O/soak.txt
+tail -4 $O/pytest.txt 2>/dev/null; tail -2 $O/soak.txt; head -c 400 $O/bench.json; echo; tail -2 $O/bench.err; tail -1 $O/parity_sweep.log
