@@ -174,17 +174,23 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// finalize_kernel: one workgroup = 1008 output positions (+8 halo each side) of one (b,h);
-// 256 threads x 4 consecutive keys.  Row loads are issued 8 rows at a time (one round trip per 8 rows).
+// finalize_kernel: one workgroup = 1024 output positions of one (b,h); 256 threads x 4 consecutive keys.  Row loads are
+// issued 8 rows at a time (one round trip per 8 rows).  The 8 + 8 halo positions the pooling window needs on either side
+// are computed as 16 * w single-probability tasks spread over the threads (round 3).  Before, a workgroup computed 1024
+// positions and wrote 1008: 33 workgroups per head at S = 32768, 1056 in all on 256 CUs - 32 CUs carried a fifth workgroup
+// and the kernel is bound by vector issue, so they set its time (7.4 us at 1024 workgroups against 8.3-8.5 at 1056,
+// measured by moving S to 32264).  1024 outputs per workgroup give 32 / 16 / 8 / 4 workgroups per head at S = 32k / 16k /
+// 8k / 4k: whole multiples of the CU count for the BASELINE shapes.
 // ------------------------------------------------------------------------------------------------
-constexpr int FN_SPAN = 1024;              // positions computed per workgroup (256 threads x 4)
-constexpr int FN_OUT = FN_SPAN - 16;       // positions written per workgroup
+constexpr int FN_OUT = 1024;               // positions computed and written per workgroup (256 threads x 4)
+constexpr int FN_HALO = 8;                 // positions on either side (pool kernel <= 17)
 
 template <typename T>
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
-  __shared__ __attribute__((aligned(16))) uint16_t sc[FN_SPAN];
+  __shared__ __attribute__((aligned(16))) uint16_t sc[FN_OUT + 2 * FN_HALO];   // index = position - first position + 8
   __shared__ float rowM[128];           // window <= 128 (check_desc)
   __shared__ float rowS[128];
+  __shared__ __attribute__((aligned(16))) float halo_p[2 * FN_HALO * 64];   // rounded probabilities of the halo tasks, [position][window row] (w <= 64 path)
 
   const int tid = threadIdx.x;
   const int bh = blockIdx.y;
@@ -195,9 +201,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   PKV_FSTAMP(0);
   const unsigned long long t_start = PKV_WGTRACE(p) ? wall_clock64() : 0ull;
 
-  const int r0 = blockIdx.x * FN_OUT - 8;
-  const int s0 = r0 + tid * 4;
-  const bool in_row = s0 >= 0 && s0 < L;
+  const int p0 = blockIdx.x * FN_OUT;
+  const int s0 = p0 + tid * 4;
+  const bool in_row = s0 < L;
   const uint16_t* lgp = reinterpret_cast<const uint16_t*>(p.logits) + rowbase * (int64_t)p.Sp + (in_row ? s0 : 0);
   // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M).
   // 32 lanes per row, 8 rows per pass; every lane issues its (<= 8 per chunk) partial loads back to
@@ -241,6 +247,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   PKV_FSTAMP(1);
 
   const uint16_t pad = (p.pool_kind == 2) ? Elem<T>::neg_inf() : (uint16_t)0;
+  // halo tasks (see below): the first pass's logit is fetched HERE, ahead of the main row loads - fetched after the main
+  // arithmetic it put one more cold round trip on the critical path (8.4 us against 7.4 for the kernel, session 8)
+  const uint16_t* lgh = reinterpret_cast<const uint16_t*>(p.logits) + rowbase * (int64_t)p.Sp;
+  const bool halo_spread = (w & (w - 1)) == 0 && w <= 64;
+  const int wsh = __builtin_ctz((unsigned)w);
+  auto halo_pos = [&](int i) { return i < FN_HALO ? p0 - FN_HALO + i : p0 + FN_OUT + (i - FN_HALO); };
+  uint32_t halo_x0 = 0;
+  if (halo_spread) {
+    const int i = tid >> wsh, r = tid & (w - 1);
+    const int pos = halo_pos(i < 2 * FN_HALO ? i : 0);
+    halo_x0 = lgh[(int64_t)r * p.Sp + ((pos >= 0 && pos < L) ? pos : 0)];
+  }
   uint16_t ov[4];
   if (in_row) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -288,7 +306,59 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   pk.x = (uint32_t)ov[0] | ((uint32_t)ov[1] << 16);
   pk.y = (uint32_t)ov[2] | ((uint32_t)ov[3] << 16);
   PKV_FSTAMP(2);
-  *reinterpret_cast<uint2*>(sc + tid * 4) = pk;
+  *reinterpret_cast<uint2*>(sc + FN_HALO + tid * 4) = pk;
+  // ---- halo: positions p0-8 .. p0-1 and p0+1024 .. p0+1031, the same arithmetic, one (position, window row) task per thread
+  //      and pass.  The w probabilities of a position sit in w consecutive lanes of ONE wave (w a power of two <= 64), go
+  //      through LDS and are summed by the group's first lane in row order - the fp32 order of the main path. ----
+  {
+    if (halo_spread) {
+      const int ntask = 2 * FN_HALO * w;
+      for (int t0 = 0; t0 < ntask; t0 += 256) {
+        const int task = t0 + tid;
+        const int i = task >> wsh, r = task & (w - 1);
+        const int pos = halo_pos(i < 2 * FN_HALO ? i : 0);
+        const bool ok = task < ntask && pos >= 0 && pos < L;
+        float pr = 0.f;
+        if (ok) {
+          const uint32_t x = t0 == 0 ? halo_x0 : (uint32_t)lgh[(int64_t)r * p.Sp + pos];
+          const pkv_f32x2 xx = {Elem<T>::to_f32((uint16_t)x), Elem<T>::to_f32((uint16_t)x)};
+          const pkv_f32x2 e2 = pkv_exp_pair(xx - pkv_f32x2{rowM[r], rowM[r]}) * pkv_f32x2{rowS[r], rowS[r]};
+          const uint32_t pk2 = round_pack2<T>(e2.x, e2.y);
+          pr = Elem<T>::to_f32((uint16_t)(pk2 & 0xffffu));
+        }
+        if (task < ntask) halo_p[task] = pr;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (task < ntask && r == 0) {
+          float acc = 0.f;
+          if (w == 8) {                                             // the runners' window: both reads in flight, then the 8 adds
+            const float4 a = *reinterpret_cast<const float4*>(halo_p + task), b = *reinterpret_cast<const float4*>(halo_p + task + 4);
+            const float hv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) acc = __builtin_fmaf(1.0f, hv[rr], acc);
+          } else {
+            for (int rr = 0; rr < w; ++rr) acc = __builtin_fmaf(1.0f, halo_p[task + rr], acc);
+          }
+          const float v = (p.reduce == 1) ? (acc / (float)w) : acc;
+          sc[i < FN_HALO ? i : FN_OUT + i] = ok ? Elem<T>::from_f32(v) : pad;
+        }
+      }
+    } else if (tid < 2 * FN_HALO) {                               // other windows: one thread per halo position
+      const int pos = halo_pos(tid);
+      const bool ok = pos >= 0 && pos < L;
+      float acc = 0.f;
+      for (int r = 0; r < w; ++r) {
+        const uint32_t x = lgh[(int64_t)r * p.Sp + (ok ? pos : 0)];
+        const pkv_f32x2 xx = {Elem<T>::to_f32((uint16_t)x), Elem<T>::to_f32((uint16_t)x)};
+        const pkv_f32x2 e2 = pkv_exp_pair(xx - pkv_f32x2{rowM[r], rowM[r]}) * pkv_f32x2{rowS[r], rowS[r]};
+        const uint32_t pk2 = round_pack2<T>(e2.x, e2.y);
+        acc = __builtin_fmaf(1.0f, Elem<T>::to_f32((uint16_t)(pk2 & 0xffffu)), acc);
+      }
+      const float v = (p.reduce == 1) ? (acc / (float)w) : acc;
+      sc[tid < FN_HALO ? tid : FN_OUT + tid] = ok ? Elem<T>::from_f32(v) : pad;
+    }
+  }
   __syncthreads();
   PKV_FSTAMP(3);
 
@@ -296,7 +366,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
     const size_t wg = 65536 + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     PKV_WGTRACE(p)[2 * wg] = t_start; PKV_WGTRACE(p)[2 * wg + 1] = wall_clock64();
   }
-  const bool writer = !(tid < 2 || tid >= 254 || s0 >= L);   // halo threads / positions past the row write nothing
+  const bool writer = s0 < L;                                 // positions past the row write nothing
   uint16_t res[4];
   const int half = p.pool_kernel >> 1;
   if (p.pool_kind == 0 || !writer) {
@@ -307,7 +377,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
     float v[20];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      const uint2 t = *reinterpret_cast<const uint2*>(sc + tid * 4 - 8 + i * 4);
+      const uint2 t = *reinterpret_cast<const uint2*>(sc + tid * 4 + i * 4);
       v[i * 4 + 0] = Elem<T>::to_f32((uint16_t)(t.x & 0xffffu));
       v[i * 4 + 1] = Elem<T>::to_f32((uint16_t)(t.x >> 16));
       v[i * 4 + 2] = Elem<T>::to_f32((uint16_t)(t.y & 0xffffu));
