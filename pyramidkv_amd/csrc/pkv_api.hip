@@ -703,7 +703,7 @@ int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, in
 int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32_t* sorted_idx,
                     int64_t idx_stride, const int32_t* head_capacity, const int32_t* cu_klen,
                     void* k_out, void* v_out, int64_t out_rows, pkv_stream_t stream) {
-  int rc = check_desc(d, false, false);
+  int rc = check_desc(d, false, false, true);      // fp32 rows move as 2D 16-bit elements (make_gather)
   if (rc) return rc;
   if (d->B != 1) return PKV_ERR_SHAPE;   // reference asserts bsz == 1 (:724)
   if (!k || !v || !sorted_idx || !head_capacity || !cu_klen || !k_out || !v_out) return PKV_ERR_NULL;
@@ -718,13 +718,13 @@ int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32
 
 int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const void* cache, const void* state,
                             const int32_t* head_lens, const int32_t* cu_klen, void* out, pkv_stream_t stream) {
-  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (dtype != PKV_BF16 && dtype != PKV_F16 && dtype != PKV_F32) return PKV_ERR_DTYPE;
   if (!cache || !state || !head_lens || !cu_klen || !out) return PKV_ERR_NULL;
   if (H < 1 || head_dim < 8 || (head_dim & 7)) return PKV_ERR_SHAPE;
   if (misaligned(cache) || misaligned(state) || misaligned(out)) return PKV_ERR_ALIGN;
   FlattenParams fp;
   fp.cache = cache; fp.state = state; fp.head_lens = head_lens; fp.cu_klen = cu_klen; fp.out = out;
-  fp.H = H; fp.row_bytes = head_dim * 2;
+  fp.H = H; fp.row_bytes = head_dim * (dtype == PKV_F32 ? 4 : 2);
   hipError_t e = launch_flatten(fp, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }

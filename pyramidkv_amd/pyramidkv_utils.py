@@ -495,6 +495,11 @@ class HeadKVCluster(_FlatPolicy):
         if getattr(self, "_cap_key", None) != key:               # the per-layer capacities are constants: upload them once
             self._cap_key, self._cap_dev = key, torch.tensor(caps, dtype=torch.int32, device=key_states.device)
         cap = self._cap_dev
+        if key_states.dtype == torch.float32:
+            # fp32 tensors (round 3): fp32 window scores -> per-head top-cap_h (32-bit radix select, k <= 4096) -> flat gather
+            attn_score = self._scores(key_states, query_states)[0]
+            sorted_idx = ops.topk(attn_score, max(1, max(caps)), k_per_row=cap)      # ValueError beyond 4096 entries per head
+            return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, caps_host=caps)
         # :840 sorts every row completely and :855 keeps the first cap_h entries: a top-k with k = max_h cap_h holds them all
         if max(caps) <= _ADA_TOPM_MAX:
             if self.pooling not in ('avgpool', 'maxpool'):

@@ -125,3 +125,36 @@ def test_f32_unsupported_entry_points_fail_loudly(P):
         P.AdaKVCluster(window_size=8, kernel_size=7, pooling="maxpool", max_capacity_prompt=64, floor=0.2, normalize=True).update_kv(k, q, v)
     with pytest.raises(ValueError):
         P.SnapKVCluster(window_size=8, max_capacity_prompt=64, merge="pivot").update_kv(k, q, v, None, 1)
+
+
+@pytest.mark.parametrize("kind,D,G", [("lattice", 128, 1), ("gauss", 128, 2), ("gauss", 64, 1)])
+def test_headkv_f32_vs_oracle(P, kind, D, G):
+    """HeadKVCluster on fp32 tensors (round 3; reference :808-878 is dtype-generic): fp32 window scores -> per-head top-cap_h
+    (32-bit radix select with per-row k) -> flat gather + var-len metadata, then the decode-time flat append in fp32.
+    Index lists == the canonical order of the kernel's own fp32 scores; K/V exact copies; vs the oracle end to end the flat
+    K/V are identical whenever the oracle's score gaps at the decisions exceed the fp32 noise (asserted on these fixtures)."""
+    Hk, S, w, cap = 3, 1500, 8, 72
+    H = Hk * G
+    q, kf, vf = make_qkv(1, H, S, D, "fp32", kind, 4100 + D)
+    k_un, v_un = kf[:, ::G].contiguous(), vf[:, ::G].contiguous()
+    k_exp = k_un[:, :, None].expand(1, Hk, G, S, D).reshape(1, H, S, D).contiguous()
+    v_exp = v_un[:, :, None].expand(1, Hk, G, S, D).reshape(1, H, S, D).contiguous()
+    hc = [[(37 * h + 5) % 300 + 1 for h in range(H)]]
+    cl = P.HeadKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, layer_idx=0, num_hidden_layers=1,
+                         head_capacity=hc)
+    kfl, vfl = cl.update_kv(k_un.to(DEV), q.to(DEV), v_un.to(DEV))
+    sg = P.ops.score_window(q.to(DEV), k_un.to(DEV), w, "maxpool", 7, "mean", kv_group=G).cpu()[0]
+    order = torch.sort(sg, dim=-1, descending=True, stable=True).indices
+    kr, vr, lens = O._flat_gather(k_exp, v_exp, [order[h, :hc[0][h]] for h in range(H)], w)
+    assert cl.head_lens.cpu().tolist() == lens and int(cl.klen_sum) == sum(lens) and cl.max_seqlen_k == max(lens)
+    assert torch.equal(kfl.cpu(), kr) and torch.equal(vfl.cpu(), vr)
+    kr2, vr2, meta = O.headkv_update_kv(k_exp, q, v_exp, w, cap, 7, "maxpool", hc, 0)
+    assert meta.head_lens.tolist() == lens
+    if kind == "lattice":                                  # exact logits: the oracle's own scores decide the same lists
+        assert torch.equal(kfl.cpu(), kr2) and torch.equal(vfl.cpu(), vr2)
+    cache = P.DynamicCacheSplitHeadFlatten()
+    cache.update(kfl, vfl, 0)
+    nk = torch.randn(1, H, 1, D)
+    knew, _ = cache.update(nk.to(DEV), nk.to(DEV), 0, {"head_lens": cl.head_lens, "cu_klen": cl.cu_klen})
+    want = O.update_flatten_view(kfl.cpu(), nk[0, :, 0], cl.head_lens.cpu(), cl.cu_klen.cpu())
+    assert torch.equal(knew.cpu(), want)
