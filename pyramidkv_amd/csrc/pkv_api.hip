@@ -31,8 +31,6 @@ int logits_nt() { static int t = env_int("PKV_LOGITS_NT", 0); return t; }
 int logits_v2() { static int t = env_int("PKV_LOGITS_V2", 1); return t; }
 int logits_v2_nt() { static int t = env_int("PKV_LOGITS_NT", 1); return t; }
 int logits_v2_wgs() { static int t = env_int("PKV_LOGITS_V2_WGS", 0); return t; }   // target workgroup count, 0 = 8 per CU
-// extra elements between the logits rows of the workspace (a multiple of 128: rows stay 256-B aligned)
-int logits_row_pad() { static int t = (env_int("PKV_SP_PAD", 0) + 127) / 128 * 128; return t; }
 int logits_fexp() { static int t = env_int("PKV_LOGITS_FEXP", 1); return t; }       // hardware exp2 in the partial statistics
 int logits_store() { static int t = env_int("PKV_LOGITS_ST", 2); return t; }        // 0 plain, 1 nontemporal, 2 write-through
 #ifdef PKV_DEBUG
@@ -126,7 +124,7 @@ struct WsLayout {
 WsLayout ws_layout(const pkv_desc* d) {
   WsLayout w;
   w.nT = (d->S + logits_tile() - 1) / logits_tile();
-  w.Sp = (d->S + 255) / 256 * 256 + logits_row_pad();
+  w.Sp = (d->S + 255) / 256 * 256;
   w.Lp = (int)align_up((size_t)(d->S - d->window), 8);
   const size_t rows = (size_t)d->B * d->H * d->window;
   const size_t es = d->dtype == PKV_F32 ? 4 : 2;                            // bytes per logit / score

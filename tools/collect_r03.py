@@ -160,6 +160,23 @@ if pb or ab:
         for k, v in (src or {}).items():
             lines.append("| %s | %s | %s |" % (k, v.get("update_kv_ms"), json.dumps(v.get("kernels_us"))))
     lines.append("")
+# issue-port counters of the headline kernels
+acc_i = defaultdict(lambda: defaultdict(list))
+for d in ("pmc_issue", "pmc_issue2"):
+    for f in sorted(glob.glob(os.path.join(G, d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
+        for r in csv.DictReader(open(f)):
+            if "pkv::" in r["Kernel_Name"]:
+                acc_i[r["Kernel_Name"].split("pkv::")[1].split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if acc_i:
+    iss = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in acc_i.items()}
+    json.dump(iss, open(os.path.join(P, "pmc_issue.json"), "w"), indent=1)
+    cols = sorted({c for v in iss.values() for c in v})
+    lines += ["## Issue-port counters of the headline kernels (rocprofv3 --pmc, two passes, per launch, summed over the chip; `pmc_issue.json`)\n",
+              "| kernel | " + " | ".join(cols) + " |", "|---|" + "---|" * len(cols)]
+    for k, v in iss.items():
+        lines.append("| %s | " % k + " | ".join("%.4g" % v.get(c, float("nan")) for c in cols) + " |")
+    lines += ["", "SQ_INSTS_VALU / (waves of the launch) = vector instructions per wave: finalize_kernel launches 1024 workgroups x 4 waves, "
+              "topk_kernel 32 x 16, gather_kernel<2,16> ~256 x 4, logits2_kernel 8192 x 4 at the headline shape.", ""]
 stats_table("prof_h2o", "H2O at S = 32768 (tools/h2o_only.py), rocprofv3 --kernel-trace --stats", 4)
 acc = defaultdict(lambda: defaultdict(list))
 for d in ("pmc_h2o_a", "pmc_h2o_b", "pmc_h2o_c"):
