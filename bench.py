@@ -82,12 +82,20 @@ def layer_budgets(P, policy, cap, w, S):
 
 
 def kernel_src_sha16():
-    """Identity of the kernel sources a PMC traffic profile belongs to (profiles/*/pmc_traffic.json records it)."""
+    """Identity of the kernel sources a PMC traffic profile belongs to (profiles/*/pmc_traffic.json records it): sha256 over the
+    .hip / .hpp files of pyramidkv_amd/csrc with // comments and whitespace runs removed - a comment edit does not orphan a
+    profile, a code edit does."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "pyramidkv_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".hpp")):
-            h.update(open(os.path.join(d, f), "rb").read())
+            code = []
+            for line in open(os.path.join(d, f), encoding="utf-8", errors="replace"):
+                line = line.split("//", 1)[0]
+                line = " ".join(line.split())
+                if line:
+                    code.append(line)
+            h.update(("\n".join(code)).encode())
     return h.hexdigest()[:16]
 
 

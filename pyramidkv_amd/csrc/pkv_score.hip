@@ -178,9 +178,8 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 // issued 8 rows at a time (one round trip per 8 rows).  The 8 + 8 halo positions the pooling window needs on either side
 // are computed as 16 * w single-probability tasks spread over the threads (round 3).  Before, a workgroup computed 1024
 // positions and wrote 1008: 33 workgroups per head at S = 32768, 1056 in all on 256 CUs - 32 CUs carried a fifth workgroup
-// and the kernel is bound by vector issue, so they set its time (7.4 us at 1024 workgroups against 8.3-8.5 at 1056,
-// measured by moving S to 32264).  1024 outputs per workgroup give 32 / 16 / 8 / 4 workgroups per head at S = 32k / 16k /
-// 8k / 4k: whole multiples of the CU count for the BASELINE shapes.
+// of a kernel that is bound by vector issue.  1024 outputs per workgroup give 32 / 16 / 8 / 4 workgroups per head at
+// S = 32k / 16k / 8k / 4k: whole multiples of the CU count for the BASELINE shapes (measured: 8.2 against 8.4 us at S = 32k).
 // ------------------------------------------------------------------------------------------------
 constexpr int FN_OUT = 1024;               // positions computed and written per workgroup (256 threads x 4)
 constexpr int FN_HALO = 8;                 // positions on either side (pool kernel <= 17)
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 
   const uint16_t pad = (p.pool_kind == 2) ? Elem<T>::neg_inf() : (uint16_t)0;
   // halo tasks (see below): the first pass's logit is fetched HERE, ahead of the main row loads - fetched after the main
-  // arithmetic it put one more cold round trip on the critical path (8.4 us against 7.4 for the kernel, session 8)
+  // arithmetic it would put one more cold round trip on the critical path
   const uint16_t* lgh = reinterpret_cast<const uint16_t*>(p.logits) + rowbase * (int64_t)p.Sp;
   const bool halo_spread = (w & (w - 1)) == 0 && w <= 64;
   const int wsh = __builtin_ctz((unsigned)w);

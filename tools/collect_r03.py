@@ -8,12 +8,9 @@ os.makedirs(P, exist_ok=True)
 
 
 def src_sha():
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "pyramidkv_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    from bench import kernel_src_sha16
+    return kernel_src_sha16()
 
 
 def first_json_line(path):

@@ -40,13 +40,10 @@ for kname, ctr in acc.items():
     out["kernels"][kname] = {"fetch_bytes_per_launch_corrected": fe, "write_bytes_per_launch": wr,
                              "hbm_bytes_per_launch": (fe or 0) + (wr or 0) if (fe is not None or wr is not None) else None,
                              "launches_fetch": len(fetch), "launches_write": len(write)}
-# identity of the kernel sources (the same hash bench.py computes): the bench line only attaches traffic that belongs to them
-import hashlib
-h = hashlib.sha256()
-csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyramidkv_amd", "csrc")
-for fn in sorted(os.listdir(csrc)):
-    if fn.endswith((".hip", ".hpp")):
-        h.update(open(os.path.join(csrc, fn), "rb").read())
-out["kernel_src_sha16"] = h.hexdigest()[:16]
+# identity of the kernel sources (the same comment-insensitive hash bench.py computes): the bench line only attaches traffic
+# that belongs to them
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_src_sha16  # noqa: E402
+out["kernel_src_sha16"] = kernel_src_sha16()
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -2,7 +2,7 @@
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/s6
+O=$R/gpurun_out/ada_session
 rm -rf $O; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_dist.py tests/test_gpu_small_shapes.py -m gpu -q --timeout 900 -k "ada or headkv or windows_up_to or wide_gqa or small_shapes or golden" > $O/pytest.txt 2>&1

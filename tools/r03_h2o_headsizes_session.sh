@@ -2,7 +2,7 @@
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/s7
+O=$R/gpurun_out/h2o_sizes
 rm -rf $O; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -q --timeout 900 -k "h2o or head_sizes" > $O/pytest.txt 2>&1
