@@ -43,8 +43,8 @@ enum pkv_status {
 };
 
 /* PKV_F32: pkv_score_window, pkv_topk(_ws), pkv_gather_compact, pkv_gather_streaming, pkv_gather_flat, pkv_compress,
- * pkv_select (window score) and pkv_update_flatten_view only, D in {64,128}, topk <= 4096; every other entry point answers
- * PKV_ERR_UNSUPPORTED (H2O, the Ada-SnapKV budgets and the merge in fp32). */
+ * pkv_select (window score), pkv_ada_budget_rows, pkv_ada_metadata and pkv_update_flatten_view only, D in {64,128},
+ * topk <= 4096; every other entry point answers PKV_ERR_UNSUPPORTED (H2O and the merge in fp32). */
 enum pkv_dtype { PKV_BF16 = 0, PKV_F16 = 1, PKV_F32 = 2 };
 enum pkv_pool { PKV_POOL_NONE = 0, PKV_POOL_AVG = 1, PKV_POOL_MAX = 2 };
 enum pkv_reduce { PKV_REDUCE_SUM = 0, PKV_REDUCE_MEAN = 1 };
@@ -169,7 +169,9 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
 /* The same budgets from the UN-SORTED score rows alone (no sort, no top-M list): what :706-719 consume of the order is, per
  * head, the sum of its `base` largest scores (:710) and how many of its adaptive scores lie above / at the global threshold
  * (:712-717) - selections and counts, computed by histograms over the whole row.  For H*base > 4096 (budget 2048), where
- * min(L, H*base) is the whole row.  scores: dtype [H][scores_stride], rows of length L <= 65536.  cu_headlens (optional,
+ * min(L, H*base) is the whole row.  scores: dtype [H][scores_stride], rows of length L <= 65536; PKV_F32 rows (L <= 32768;
+ * 32-bit keys, four radix levels; ws >= 1024 + 4*H*256*4 + 4*H*4 bytes) are accepted here and nowhere else among the budget
+ * entry points - an fp32 `sum()` ratio has no bit-level target (ATen's order depends on the host), see DESIGN.md section 5.  cu_headlens (optional,
  * int32 [H]): inclusive prefix of head_lens (:687).  host_mirror (optional): device-visible PINNED HOST int32 [H+1]: gets the
  * capacities, then host_seq in word H (release, system scope) - the host polls it instead of copy + stream synchronise.
  * The gather then needs, per head, its first cap_h entries of the canonical order: pkv_topk with k_per_row = head_capacity. */

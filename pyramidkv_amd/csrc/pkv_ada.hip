@@ -29,6 +29,7 @@ struct AdaWs {           // layout of the workspace handed to pkv_ada_budget
   int32_t* cum_lo;       // [H][256]  #entries with key >= (b1<<8 | c)
   uint16_t* list;        // [H][Lpad] sorted values of every head as staged by the first kernel (null: re-stage from the inputs)
   int Lpad;
+  const int32_t* above_hi;   // optional [H]: entries above every key that shares cum_hi's prefix (more than two radix levels: fp32 keys)
 };
 
 template <typename T>
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
   const int b2 = find_level(ws.cum_lo, p.H, total, s_sum, &s_b, tid);
   int gt = 0, eq = 0;
   if (tid < p.H) {
-    gt = b2 < 255 ? ws.cum_lo[tid * 256 + b2 + 1] : (b1 < 255 ? ws.cum_hi[tid * 256 + b1 + 1] : 0);
+    gt = b2 < 255 ? ws.cum_lo[tid * 256 + b2 + 1] : (b1 < 255 ? ws.cum_hi[tid * 256 + b1 + 1] : (ws.above_hi ? ws.above_hi[tid] : 0));
     eq = ws.cum_lo[tid * 256 + b2] - gt;
   }
   // need = total - sum_h gt_h
@@ -450,8 +451,19 @@ __global__ void ada_metadata_kernel(int H, int w, const int32_t* cap, int32_t* h
   }
 }
 
+// the shared last step for callers that build their own count tables (pkv_f32.hip: four radix levels of 32-bit keys; the
+// last two levels' tables play cum_hi / cum_lo)
+hipError_t launch_ada_final(const BudgetParams& p, int32_t* cum_hi, int32_t* cum_lo, const int32_t* above_hi, hipStream_t st) {
+  AdaWs ws;
+  ws.ratio = nullptr; ws.cum_hi = cum_hi; ws.cum_lo = cum_lo; ws.list = nullptr; ws.Lpad = 0; ws.above_hi = above_hi;
+  hipLaunchKernelGGL(ada_final_kernel, dim3(1), dim3(256), 0, st, p, ws, p.one_minus_floor, p.window, p.head_lens_out,
+                     p.cu_klen_out, p.cu_headlens_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st) {
   AdaWs ws;
+  ws.above_hi = nullptr;
   char* base = reinterpret_cast<char*>(p.ws);
   ws.ratio = reinterpret_cast<float*>(base);
   ws.cum_hi = reinterpret_cast<int32_t*>(base + 1024);

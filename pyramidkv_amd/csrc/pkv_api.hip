@@ -387,7 +387,7 @@ const char* pkv_strerror(int s) {
 }
 
 int pkv_last_hip_error(void) { return g_last_hip; }
-void pkv_set_last_hip_error(int e) { g_last_hip = e; }   /* internal: other translation units of libpkv report through it */
+__attribute__((visibility("hidden"))) void pkv_set_last_hip_error(int e) { g_last_hip = e; }   /* internal (not exported): other translation units of libpkv report through it */
 
 
 size_t pkv_workspace_bytes(const pkv_desc* d) {
@@ -604,12 +604,12 @@ int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores,
                         double floor_ratio, int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens,
                         int32_t* cu_klen, int32_t* cu_headlens, int32_t* host_mirror, int32_t host_seq, void* ws, size_t ws_bytes,
                         pkv_stream_t stream) {
-  if (dtype != PKV_BF16 && dtype != PKV_F16) return PKV_ERR_DTYPE;
+  if (dtype != PKV_BF16 && dtype != PKV_F16 && dtype != PKV_F32) return PKV_ERR_DTYPE;
   if (!scores || !head_capacity || !ws) return PKV_ERR_NULL;
   if ((head_lens == nullptr) != (cu_klen == nullptr)) return PKV_ERR_NULL;
   if (H < 1 || H > 256 || L < 1 || base_capacity < 1 || base_capacity > L || scores_stride < L) return PKV_ERR_SHAPE;
-  if (L > 65536) return PKV_ERR_UNSUPPORTED;          // a row lives in the registers of one 1024-thread workgroup
-  if (ws_bytes < 1024 + (size_t)2 * H * 256 * 4) return PKV_ERR_WORKSPACE;
+  if (L > (dtype == PKV_F32 ? budget_f32_max_row() : 65536)) return PKV_ERR_UNSUPPORTED;   // a row lives in the registers of one 1024-thread workgroup
+  if (ws_bytes < (dtype == PKV_F32 ? 1024 + (size_t)4 * H * 256 * 4 + (size_t)4 * H * 4 : 1024 + (size_t)2 * H * 256 * 4)) return PKV_ERR_WORKSPACE;
   BudgetParams bp;
   bp.sorted_val = nullptr; bp.sorted_idx = nullptr; bp.idx_stride = 0; bp.scores = scores; bp.scores_stride = scores_stride;
   bp.Lrow = L; bp.H = H; bp.L = L; bp.base = base_capacity;
@@ -620,7 +620,7 @@ int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores,
   bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.adaptive_out = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
-  hipError_t e = launch_budget(dtype, bp, st);
+  hipError_t e = dtype == PKV_F32 ? launch_budget_f32(bp, st) : launch_budget(dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }
 

@@ -320,6 +320,185 @@ __global__ __launch_bounds__(1024) void topk_f32_kernel(TopkParams p) {
   for (int j = tid; j < k; j += 1024) out[j] = (int32_t)(0xffffffffu - (uint32_t)comp[j]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ada-SnapKV budgets from fp32 score rows (reference pyramidkv_utils.py:706-719 on fp32 tensors; round 3).
+// The scheme of pkv_ada.hip's un-sorted kernels with 32-bit keys: four 8-bit radix levels instead of two, one launch per
+// level (the global digit of a level is a sum over all heads), one 1024-thread workgroup per head, the row in registers
+// (<= 32768 scores).  Level 0 also makes the head's ratio (:710): exact radix select of the base-th largest raw score, the
+// two sums in double, rounded to fp32, divided in fp32.  ATen sums fp32 tensors in an order its vector width decides, so
+// there is no bit-level target for that quotient: against the CPU oracle the budgets agree up to the rare entry that sits
+// within an ulp of the global threshold (tests/test_gpu_f32.py states the bar).
+//   cum[level][h][d]  = number of adaptive keys of head h that are >= ((prefix_level << 8 | d) << shift_level)
+//   above[level][h]   = number of adaptive keys of head h above every key that shares prefix_level
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float f32_key_value(uint32_t key) {           // inverse of f32_key
+  return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+
+__global__ __launch_bounds__(1024) void ada_f32_level_kernel(BudgetParams p, float* ratio_ws, int32_t* cum, int32_t* above, int level) {
+  __shared__ uint32_t hist[256];
+  __shared__ int64_t s_sum[256];
+  __shared__ uint32_t sh_digit, sh_kk;
+  __shared__ int s_b;
+  __shared__ double red[2][16];
+  __shared__ uint32_t wsum[16];
+  __shared__ float s_ratio;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, L = p.Lrow, H = p.H;
+  const float* row = reinterpret_cast<const float*>(p.scores) + (int64_t)h * p.scores_stride;
+  float sv[TKF_NV];
+#pragma unroll
+  for (int j = 0; j < TKF_NV; ++j) {
+    const int i = j * 1024 + tid;
+    sv[j] = row[i < L ? i : L - 1];
+  }
+  // one radix-histogram round over this thread's keys: digit `shift` of the keys for which take(j) holds.  Scores of one row
+  // share sign and most exponent bits: one aggregated LDS atomic for the first active lane's digit, plain atomics for the rest
+  auto hist_round = [&](auto&& key_of, auto&& take, int shift) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TKF_NV; ++j) {
+      const int i = j * 1024 + tid;
+      bool act = i < L && take(j);
+      const uint32_t dg = (key_of(j) >> shift) & 255u;
+      const unsigned long long m = __ballot(act);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t dl = (uint32_t)__shfl((int)dg, leader, 64);
+        const unsigned long long same = __ballot(act && dg == dl);
+        if (lane == leader) atomicAdd(&hist[dl], (uint32_t)__popcll(same));
+        act = act && dg != dl;
+      }
+      if (act) atomicAdd(&hist[dg], 1u);
+    }
+    __syncthreads();
+  };
+  float ratio = 1.0f;
+  if (level == 0) {
+    if (p.normalize) {
+      // base-th largest raw score (32-bit key, four rounds), then the two sums of :710
+      uint32_t prefix = 0, mask = 0, kk = (uint32_t)p.base;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist_round([&](int j) { return f32_key(sv[j]); }, [&](int j) { return (f32_key(sv[j]) & mask) == prefix; }, shift);
+        if (wave == 0) {                                   // digits from the top: lane l holds 255-4l .. 252-4l
+          uint32_t c[4], sm = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { c[j] = hist[255 - (4 * lane + j)]; sm += c[j]; }
+          const uint32_t incl = wave_incl_scan_u32(sm), excl = incl - sm;
+          if (excl < kk && kk <= incl) {
+            uint32_t run = excl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (run < kk && kk <= run + c[j]) { sh_digit = 255 - (4 * lane + j); sh_kk = kk - run; }
+              run += c[j];
+            }
+          }
+        }
+        __syncthreads();
+        prefix |= sh_digit << shift;
+        mask |= 0xffu << shift;
+        kk = sh_kk;
+        __syncthreads();
+      }
+      const uint32_t T = prefix;                           // kk entries equal to T belong to the top `base`
+      double st = 0.0, sa = 0.0;
+#pragma unroll
+      for (int j = 0; j < TKF_NV; ++j) {
+        const int i = j * 1024 + tid;
+        if (i < L) {
+          const double x = (double)sv[j];
+          sa += x;
+          if (f32_key(sv[j]) > T) st += x;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) { st += __shfl_xor(st, o, 64); sa += __shfl_xor(sa, o, 64); }
+      if (lane == 0) { red[0][wave] = st; red[1][wave] = sa; }
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0, a = 0.0;
+        for (int w2 = 0; w2 < 16; ++w2) { t += red[0][w2]; a += red[1][w2]; }
+        t += (double)kk * (double)f32_key_value(T);
+        s_ratio = (float)t / (float)a;                     // fp32 sums, fp32 division (:710)
+        ratio_ws[h] = s_ratio;
+      }
+      __syncthreads();
+      ratio = s_ratio;
+    } else if (tid == 0) {
+      ratio_ws[h] = 1.0f;
+    }
+  } else {
+    ratio = ratio_ws[h];
+  }
+  const int norm = p.normalize;
+  auto akey = [&](int j) { return f32_key(norm ? sv[j] * ratio : sv[j]); };      // adaptive_attn_score * ratio_weight (:711)
+  // the digits the earlier levels settled: largest d with sum_h cum[lv][h][d] >= H * base
+  const int64_t total = (int64_t)H * p.base;
+  uint32_t gprefix = 0;
+  for (int lv = 0; lv < level; ++lv) {
+    if (tid < 256) {
+      const int32_t* c = cum + (int64_t)lv * H * 256;
+      int64_t sm = 0;
+      for (int h0 = 0; h0 < H; h0 += 32) {
+        int32_t v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = c[(h0 + j < H ? h0 + j : H - 1) * 256 + tid];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) sm += (h0 + j < H) ? v[j] : 0;
+      }
+      s_sum[tid] = sm;
+    }
+    __syncthreads();
+    if (tid < 256 && s_sum[tid] >= total && (tid == 255 || s_sum[tid + 1] < total)) s_b = tid;
+    __syncthreads();
+    gprefix = (gprefix << 8) | (uint32_t)s_b;
+    __syncthreads();
+  }
+  const int shift = 24 - 8 * level;
+  hist_round(akey, [&](int j) { return level == 0 || (akey(j) >> (shift + 8)) == gprefix; }, shift);
+  uint32_t ab = 0;                                          // keys above everything that shares the prefix
+  if (level > 0) {
+#pragma unroll
+    for (int j = 0; j < TKF_NV; ++j) {
+      const int i = j * 1024 + tid;
+      ab += (i < L && (akey(j) >> (shift + 8)) > gprefix) ? 1u : 0u;
+    }
+    ab = wave_sum_u32(ab);
+    if (lane == 0) wsum[wave] = ab;
+  }
+  {                                                         // suffix sums of the 256 digit counts (4 waves x 64 digits)
+    const uint32_t c = tid < 256 ? hist[tid] : 0u;
+    const uint32_t incl = wave_incl_scan_u32(c);
+    const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t suf = wtot - incl + c;
+    __syncthreads();                                        // hist reads done; wsum complete
+    if (lane == 0 && wave < 4) hist[wave] = wtot;
+    uint32_t abv = 0;
+    if (level > 0) for (int w2 = 0; w2 < 16; ++w2) abv += wsum[w2];
+    __syncthreads();
+    if (tid < 256) {
+      for (int w2 = wave + 1; w2 < 4; ++w2) suf += hist[w2];
+      cum[((int64_t)level * H + h) * 256 + tid] = (int32_t)(suf + abv);
+    }
+    if (tid == 0) above[level * H + h] = (int32_t)abv;
+  }
+}
+
+int budget_f32_max_row() { return TKF_NV * 1024; }
+
+hipError_t launch_budget_f32(const BudgetParams& p, hipStream_t st) {
+  char* base = reinterpret_cast<char*>(p.ws);
+  float* ratio = reinterpret_cast<float*>(base);
+  int32_t* cum = reinterpret_cast<int32_t*>(base + 1024);
+  int32_t* above = cum + (size_t)4 * p.H * 256;
+  for (int level = 0; level < 4; ++level)
+    hipLaunchKernelGGL(ada_f32_level_kernel, dim3(p.H), dim3(1024), 0, st, p, ratio, cum, above, level);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return launch_ada_final(p, cum + (size_t)2 * p.H * 256, cum + (size_t)3 * p.H * 256, above + 2 * p.H, st);
+}
+
 hipError_t launch_logits_f32(const LogitsParams& p, hipStream_t st) {
   dim3 grid(p.nT, p.B * (p.H / p.G));
   if (p.D == 64) PKV_KLAUNCH(logits_f32_kernel<4>, grid, dim3(256), 0, st, p);

@@ -5,7 +5,7 @@
 #include <stdint.h>
 
 // records the hipError_t pkv_last_hip_error() reports for this thread (defined in pkv_api.hip; internal to libpkv)
-extern "C" void pkv_set_last_hip_error(int e);
+extern "C" __attribute__((visibility("hidden"))) void pkv_set_last_hip_error(int e);
 
 namespace pkv {
 
@@ -198,6 +198,9 @@ hipError_t launch_topk_merge_finish(int rows, int k, const int32_t* cand_idx, in
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);
 hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
+hipError_t launch_ada_final(const BudgetParams& p, int32_t* cum_hi, int32_t* cum_lo, const int32_t* above_hi, hipStream_t st);
+hipError_t launch_budget_f32(const BudgetParams& p, hipStream_t st);      // fp32 score rows (pkv_f32.hip), ws: 1024 + 4*H*256*4 + 4*H*4 bytes
+int budget_f32_max_row();
 hipError_t launch_ada_metadata(int H, int w, const int32_t* cap, int32_t* head_lens, int32_t* cu_klen, hipStream_t st,
                                int32_t* cu_headlens = nullptr);
 hipError_t launch_flatten(const FlattenParams& p, hipStream_t st);

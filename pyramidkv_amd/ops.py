@@ -303,7 +303,7 @@ def ada_budget_rows(scores: torch.Tensor, base_capacity: int, floor_ratio: float
     dev = scores.device
     meta = torch.empty(4 * H + 1, dtype=torch.int32, device=dev)
     cap, head_lens, cu, cuh = meta[:H], meta[H:2 * H], meta[2 * H:3 * H + 1], meta[3 * H + 1:]
-    nb = 1024 + 2 * H * 256 * 4
+    nb = 1024 + (4 if scores.dtype == torch.float32 else 2) * H * 256 * 4 + 4 * H * 4
     with torch.cuda.device(dev):
         ws = workspace(nb, dev)
         N.check(N.lib.pkv_ada_budget_rows(N.dtype_code(scores.dtype), H, L, scores.data_ptr(), scores.stride(0), base_capacity,

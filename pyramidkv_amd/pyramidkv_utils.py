@@ -426,7 +426,7 @@ class AdaKVCluster(_FlatPolicy):
         # budgets AND hold every index the gather takes (cap_h <= M).  They come from the top-k kernel (no full sort);
         # score -> top-M -> budgets -> metadata is ONE C call.
         M = min(L, num_heads * self.base_capacity)
-        if M <= _ADA_TOPM_MAX:
+        if M <= _ADA_TOPM_MAX and key_states.dtype != torch.float32:      # fp32 tensors take the un-sorted-rows path below
             if self.pooling not in ('avgpool', 'maxpool'):
                 raise ValueError('Pooling method not supported')
             mirror = None
@@ -447,6 +447,8 @@ class AdaKVCluster(_FlatPolicy):
         # then every head's first cap_h entries of the canonical order from one top-k launch with per-head k.  Rows or
         # capacities beyond one top-k workgroup keep the complete sort.
         attn_score = self._scores(key_states, query_states)[0]                       # [H, L]   :647-672
+        if key_states.dtype == torch.float32 and L > 32768:
+            raise ValueError("Ada-SnapKV on fp32 tensors: rows up to 32768 past tokens")
         if L <= 65536:
             mirror = None
             if _cfg.host_poll:
@@ -464,6 +466,8 @@ class AdaKVCluster(_FlatPolicy):
             if top_idx is not None:
                 return self._flat_from_capacity(key_states, value_states, top_idx, cap, num_heads, caps_host=caps,
                                                 meta=(head_lens, cu, cuh))
+            if key_states.dtype == torch.float32:
+                raise ValueError("Ada-SnapKV on fp32 tensors: head capacities up to 4096 past tokens")
         sorted_idx, sorted_val = ops.sort_rows(attn_score)                           # :706
         cap = ops.ada_budget(sorted_val, self.base_capacity, self.floor_ratio, bool(self.normalize))  # :709-719
         return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads)
