@@ -50,6 +50,16 @@ def test_strerror_and_argument_validation_without_gpu(P):
     d.k_stride[2] = 130                                        # rows not 16-byte aligned
     assert N.lib.pkv_gather_streaming(d, 16, 16, 16, 16, None) == -3
     assert N.lib.pkv_topk(0, 1, 100000, 5, 16, 100000, None, 16, 5, None) == -5   # L beyond the LDS limit
+    # pkv_ada_budget_rows (round 3): budgets from un-sorted rows; 16-bit rows up to 65536 scores, fp32 rows up to 32768
+    br = lambda dtype, H, L, base, ws_bytes, scores=16, cap=16, hl=16, cu=16: N.lib.pkv_ada_budget_rows(   # noqa: E731
+        dtype, H, L, scores, L, base, 0.2, 1, 8, cap, hl, cu, None, None, 0, 16, ws_bytes, None)
+    assert br(7, 4, 1000, 100, 1 << 20) == -1                          # dtype
+    assert br(0, 4, 1000, 100, 1 << 20, scores=None) == -7             # null scores
+    assert br(0, 4, 1000, 100, 1 << 20, hl=None) == -7                 # head_lens without cu_klen
+    assert br(0, 300, 1000, 100, 1 << 20) == -2                        # more than 256 heads
+    assert br(0, 4, 1000, 1001, 1 << 20) == -2                         # base capacity beyond the row
+    assert br(0, 4, 70000, 100, 1 << 20) == -5 and br(2, 4, 40000, 100, 1 << 20) == -5   # rows beyond one workgroup's registers
+    assert br(0, 4, 1000, 100, 1024) == -4 and br(2, 4, 1000, 100, 1024 + 2 * 4 * 256 * 4) == -4   # fp32 needs four count tables
     assert N.lib.pkv_topk(0, 1, 100, 500, 16, 100, None, 16, 500, None) == -2     # k > L
     assert N.lib.pkv_workspace_bytes(d) > 0
     # fp32 tensors (PKV_F32 = 2): window policies, D in {64, 128}, topk <= 4096; everything else is PKV_ERR_UNSUPPORTED
