@@ -518,11 +518,43 @@ __global__ __launch_bounds__(256) void logits2_kernel(LogitsParams p) {
 #pragma unroll
   for (int n = 0; n < NCT; ++n) { m_run[n] = -INFINITY; l_run[n] = 0.f; }
 
+  // logits of stage h: C rows x 256 B out of tile[h & 1], 16 B per item
+  auto store_stage = [&](int h) {
+    if (PKV_ABLATE(p) == 1 || PKV_ABLATE(p) == 2 || PKV_ABLATE(p) == 4) return;    // measurement aids: no logits store
+    const uint16_t* tile = tile0 + (h & 1) * C * LROW;
+    const int s_stage = start + h * HT;
+    for (int it = tid; it < C * 16; it += 256) {
+      const int row = it >> 4, ch = it & 15;
+      const uint4 v = *reinterpret_cast<const uint4*>(tile + row * LROW + ch * 8);
+      if (PKV_ABLATE(p) == 3) {              // measurement aid: the same stores into a per-workgroup 2 KB patch that stays in L2
+        *reinterpret_cast<uint4*>(lg_out + ((int64_t)((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 128 + it) * 8) = v;
+        continue;
+      }
+      uint16_t* dst = lg_out + (rowbase + row) * (int64_t)p.Sp + s_stage + ch * 8;
+      if (p.st_mode == 2) {
+        // write-through (sc1): the 16.8 MB of logits leave the XCD's L2 while the K stream is still running instead of
+        // as one write-back burst at the kernel boundary (MI355X_MICROARCH.md: a boundary costs + dirty bytes / 6 TB/s)
+        const uint32_t voff = (uint32_t)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(lg_out));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), lg_rsrc, voff, 0, 16);
+      } else if (p.st_mode == 1) {
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
+      } else {
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
+    }
+  };
+
   for (int h = 0; h < nh; ++h) {
     // land stage h in this wave's staging area, then put stage h+1 in flight
 #pragma unroll
     for (int j = 0; j < 8; ++j) kst[j * 64 + lane] = pre[j];
     if (h + 1 < nh) issue(h + 1);       // nothing else is outstanding here, so the branch costs no extra wait
+    // The logits of stage h-1 leave HERE, one stage late: vmcnt counts loads and stores in one in-order queue, so the wait
+    // for the K rows of stage h+1 (top of the next iteration) also waits for every store issued before it.  Stores issued
+    // at the end of a stage were acknowledged at that wait - a full write-through round trip exposed per stage; issued
+    // here they have the whole stage to complete.  (tile[(h-1) & 1] is complete since the barrier that closed stage h-1 and
+    // is not written again before the barrier that closes this stage.)
+    if (h > 0) store_stage(h - 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -599,30 +631,9 @@ __global__ __launch_bounds__(256) void logits2_kernel(LogitsParams p) {
       }
       m_run[n] = m_new;
     }
-    if (PKV_ABLATE(p) == 1 || PKV_ABLATE(p) == 2) continue;        // measurement aid: no logits store
     __syncthreads();
-    if (PKV_ABLATE(p) == 4) continue;        // measurement aid: barrier only
-    // logits of the stage: C rows x 256 B, 16 B per item
-    for (int it = tid; it < C * 16; it += 256) {
-      const int row = it >> 4, ch = it & 15;
-      const uint4 v = *reinterpret_cast<const uint4*>(tile + row * LROW + ch * 8);
-      if (PKV_ABLATE(p) == 3) {              // measurement aid: the same stores into a per-workgroup 2 KB patch that stays in L2
-        *reinterpret_cast<uint4*>(lg_out + ((int64_t)((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 128 + it) * 8) = v;
-        continue;
-      }
-      uint16_t* dst = lg_out + (rowbase + row) * (int64_t)p.Sp + s_stage + ch * 8;
-      if (p.st_mode == 2) {
-        // write-through (sc1): the 16.8 MB of logits leave the XCD's L2 while the K stream is still running instead of
-        // as one write-back burst at the kernel boundary (MI355X_MICROARCH.md: a boundary costs + dirty bytes / 6 TB/s)
-        const uint32_t voff = (uint32_t)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(lg_out));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), lg_rsrc, voff, 0, 16);
-      } else if (p.st_mode == 1) {
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
-      } else {
-        *reinterpret_cast<uint4*>(dst) = v;
-      }
-    }
   }
+  store_stage(nh - 1);
   // per column: merge the 4 key-group lanes, then the 4 waves, one partial per (workgroup, row)
 #pragma unroll
   for (int n = 0; n < NCT; ++n) {
