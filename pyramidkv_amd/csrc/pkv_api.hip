@@ -492,16 +492,19 @@ int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int
 }
 
 namespace {
-struct MergeWs { size_t off_mask, off_n, off_drop, off_pivot, off_tn, total; int ntp; };
+struct MergeWs { size_t off_mask, off_bad, off_n, off_drop, off_pivot, off_tn, off_start, off_list, total; int ntp; };
 MergeWs merge_ws(const pkv_desc* d) {
   MergeWs m;
   size_t o = 0;
   m.ntp = (int)align_up((size_t)(d->topk + d->window), 8);
   m.off_mask = o;  o = align_up(o + (size_t)d->S, 256);
+  m.off_bad = o;   o = align_up(o + (size_t)d->B * d->H * 4, 256);         // directly behind the mask: one memset clears both
   m.off_n = o;     o = align_up(o + 4, 256);
   m.off_drop = o;  o = align_up(o + (size_t)d->S * 4, 256);
   m.off_pivot = o; o = align_up(o + (size_t)d->B * d->H * d->S * 4, 256);
-  m.off_tn = o;    o = align_up(o + (size_t)d->B * d->H * m.ntp * 128 * 2, 256);
+  m.off_tn = o;    o = align_up(o + (size_t)d->B * d->H * m.ntp * d->D * 2, 256);
+  m.off_start = o; o = align_up(o + (size_t)d->B * d->H * (d->topk + d->window + 1) * 4, 256);
+  m.off_list = o;  o = align_up(o + (size_t)d->B * d->H * d->S * 4, 256);
   m.total = o;
   return m;
 }
@@ -519,7 +522,7 @@ int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int
   if (!k || !v || !idx || !k_out || !v_out || !ws) return PKV_ERR_NULL;
   if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out) || misaligned(ws)) return PKV_ERR_ALIGN;
   if (idx_stride < d->topk) return PKV_ERR_SHAPE;
-  if (d->D != 128) return PKV_ERR_UNSUPPORTED;
+  if ((size_t)d->S > merge_max_seq() || d->topk + d->window > 65535) return PKV_ERR_UNSUPPORTED;   // LDS bitmap; 16-bit kept-row numbers in the pivot keys
   MergeWs m = merge_ws(d);
   if (ws_bytes < m.total) return PKV_ERR_WORKSPACE;
   char* w = static_cast<char*>(ws);
@@ -528,9 +531,10 @@ int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int
   p.B = d->B; p.H = d->H; p.S = d->S; p.w = d->window; p.k = d->topk; p.G = d->kv_group;
   p.ks_b = d->k_stride[0]; p.ks_h = d->k_stride[1]; p.ks_s = d->k_stride[2];
   p.vs_b = d->v_stride[0]; p.vs_h = d->v_stride[1]; p.vs_s = d->v_stride[2];
-  p.mask = reinterpret_cast<uint8_t*>(w + m.off_mask); p.ndrop = reinterpret_cast<int32_t*>(w + m.off_n);
+  p.mask = reinterpret_cast<uint8_t*>(w + m.off_mask); p.kept_bad = reinterpret_cast<int32_t*>(w + m.off_bad); p.ndrop = reinterpret_cast<int32_t*>(w + m.off_n);
   p.drop = reinterpret_cast<int32_t*>(w + m.off_drop); p.pivot = reinterpret_cast<int32_t*>(w + m.off_pivot);
-  p.tn = w + m.off_tn; p.ntp = m.ntp;
+  p.tn = w + m.off_tn; p.ntp = m.ntp; p.D = d->D;
+  p.bstart = reinterpret_cast<int32_t*>(w + m.off_start); p.blist = reinterpret_cast<int32_t*>(w + m.off_list);
   hipError_t e = launch_merge(d->dtype, p, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }

@@ -158,8 +158,12 @@ struct MergeParams {         // LOOK-M pivot merge (pkv_merge.hip)
   int32_t* ndrop;            // number of dropped positions
   int32_t* drop;             // [S] dropped positions, ascending
   int32_t* pivot;            // [B*H][S] kept-row number (KEY order) every dropped row merges into
-  void* tn;                  // [B*H][ntp][128] unit-norm kept keys
+  void* tn;                  // [B*H][ntp][D] unit-norm kept keys
   int ntp;
+  int D;                     // head size: 64, 128 or 256
+  int32_t* kept_bad;         // [B*H] != 0: a kept key of the head has no finite unit-norm form (zeroed with the mask)
+  int32_t* bstart;           // [B*H][k+w+1] first entry of every kept row's group in blist (last = number of dropped rows)
+  int32_t* blist;            // [B*H][S] dropped positions grouped by the kept row they merge into
 };
 
 struct FlattenParams {
@@ -205,6 +209,7 @@ hipError_t launch_ada_metadata(int H, int w, const int32_t* cap, int32_t* head_l
                                int32_t* cu_headlens = nullptr);
 hipError_t launch_flatten(const FlattenParams& p, hipStream_t st);
 hipError_t launch_merge(int dtype, const MergeParams& p, hipStream_t st);
+size_t merge_max_seq();      // longest sequence the merge takes (LDS bitmap of the scatter kernel)
 hipError_t launch_debug_exp(const float* in, float* out, int64_t n, hipStream_t st);
 hipError_t launch_debug_round(int dtype, const float* in, uint16_t* out, int64_t n, hipStream_t st);
 // fp32 tensors (pkv_f32.hip)

@@ -14,7 +14,9 @@
 //     ATen's scatter_reduce(mean, include_self) accumulates in fp32, rounds the SUM, then divides by a model-dtype count.
 //
 // Kernels: mark (union bitmap) -> droplist (ordered compaction) -> targets (unit-norm kept keys) -> pivot (MFMA cosine
-// similarity + first-maximum argmax) -> scatter (per kept row: ordered walk over the dropped rows that chose it).
+// similarity + first-maximum argmax) -> bucket (per head: the dropped rows grouped by the kept row they chose, counting
+// sort) -> scatter (per kept row: its group put in ascending order through an LDS bitmap, then the ordered walk).
+// Head sizes 64 / 128 / 256: the kernels are templated on the MFMA k-steps KS = D / 32, like the H2O kernels.
 // Roofline: the dominant traffic is every DROPPED key and value row read once by pivot (K) and once by scatter (K, V):
 // 3 * (S - |union|) * D * e per head; the contraction is 2*(S-|union|)*(k+w)*D flop per head (MFMA, far from bound).
 #include "pkv_common.hpp"
@@ -37,25 +39,57 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(MergeParams p) {
 }
 
 // ---- 2. dropped positions in ascending order (ordered compaction by one workgroup) ----
+// Thread t owns the positions [t*per, (t+1)*per), per a multiple of 16: it counts its un-selected positions from 16-byte
+// loads of the mask, one block-wide exclusive scan places the threads, and a second walk over the same (cached) bytes writes
+// the positions.  (The first version walked S in rounds of 1024 with two barriers each: 25 us at S = 32768.)
 __global__ __launch_bounds__(1024) void merge_droplist_kernel(MergeParams p) {
   __shared__ uint32_t wtot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t run = 0;
-  for (int s0 = 0; s0 < p.S; s0 += 1024) {
-    const int s = s0 + tid;
-    const bool drop = s < p.S && p.mask[s] == 0;
-    const uint64_t bal = __ballot(drop);
-    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-    if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
-    __syncthreads();
-    uint32_t lower = 0, all = 0;
+  const int per = (((p.S + 1023) >> 10) + 15) & ~15;
+  const int s0 = tid * per;
+  auto zero_bytes = [&](int s, uint32_t (&wd)[4]) -> bool {               // the 16 mask bytes at s (positions >= S read as selected)
+    if (s + 16 <= p.S) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p.mask + s);        // mask is 256-byte aligned, s a multiple of 16
+      wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w;
+      return true;
+    }
 #pragma unroll
-    for (int w2 = 0; w2 < 16; ++w2) { const uint32_t c = wtot[w2]; all += c; lower += w2 < wave ? c : 0u; }
-    if (drop) p.drop[run + lower + before] = s;
-    run += all;
-    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) { const int sp = s + q * 4 + bq; x |= (uint32_t)(sp < p.S ? p.mask[sp] : 1) << (8 * bq); }
+      wd[q] = x;
+    }
+    return s < p.S;
+  };
+  uint32_t cnt = 0;
+  for (int c = 0; c < per && s0 + c < p.S; c += 16) {
+    uint32_t wd[4];
+    zero_bytes(s0 + c, wd);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) cnt += ((wd[q] >> (8 * bq)) & 0xffu) == 0u ? 1u : 0u;
   }
-  if (tid == 0) *p.ndrop = (int32_t)run;
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t lower = 0, all = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < 16; ++w2) { const uint32_t c = wtot[w2]; all += c; lower += w2 < wave ? c : 0u; }
+  uint32_t at = lower + incl - cnt;
+  for (int c = 0; c < per && s0 + c < p.S; c += 16) {
+    uint32_t wd[4];
+    zero_bytes(s0 + c, wd);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq)
+        if (((wd[q] >> (8 * bq)) & 0xffu) == 0u) p.drop[at++] = s0 + c + q * 4 + bq;
+  }
+  if (tid == 0) *p.ndrop = (int32_t)all;
 }
 
 // kept row j of the KEY order [window, selected] (:146): source position in K
@@ -68,33 +102,49 @@ __device__ __forceinline__ int val_target_pos(const MergeParams& p, const int32_
 }
 
 // ---- 3. unit-norm kept keys: tn[bh][j][:] = dtype(t_j / dtype(|t_j|)) ----
-template <typename T>
+template <typename T, int KS>
 __global__ __launch_bounds__(256) void merge_targets_kernel(MergeParams p) {
+  constexpr int D = KS * 32, EPL = D / 64;                                         // elements per lane: 1, 2 or 4
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
   const int j = blockIdx.x * 4 + wave;
   if (j >= p.k + p.w) return;
   const int32_t* idx_row = p.idx + (int64_t)bh * p.idx_stride;
   const int pos = key_target_pos(p, idx_row, j);
-  const uint16_t* src = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h + (int64_t)pos * p.ks_s;
-  const uint32_t two = reinterpret_cast<const uint32_t*>(src)[lane];                 // 2 of the 128 elements per lane
-  const float x0 = Elem<T>::to_f32((uint16_t)(two & 0xffffu)), x1 = Elem<T>::to_f32((uint16_t)(two >> 16));
-  const float n2 = wave_sum(x0 * x0 + x1 * x1);
+  const uint16_t* src = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h + (int64_t)pos * p.ks_s + lane * EPL;
+  uint16_t raw[EPL];
+  if constexpr (EPL == 1) raw[0] = src[0];
+  else if constexpr (EPL == 2) { const uint32_t two = *reinterpret_cast<const uint32_t*>(src); raw[0] = (uint16_t)(two & 0xffffu); raw[1] = (uint16_t)(two >> 16); }
+  else { const uint2 four = *reinterpret_cast<const uint2*>(src); raw[0] = (uint16_t)(four.x & 0xffffu); raw[1] = (uint16_t)(four.x >> 16); raw[2] = (uint16_t)(four.y & 0xffffu); raw[3] = (uint16_t)(four.y >> 16); }
+  float x[EPL], sq = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { x[e] = Elem<T>::to_f32(raw[e]); sq += x[e] * x[e]; }
+  const float n2 = wave_sum(sq);
   const float n = Elem<T>::to_f32(Elem<T>::from_f32(sqrtf(n2)));                    // torch.norm -> model dtype
-  const uint32_t out = round_pack2<T>(x0 / n, x1 / n);                               // k / norm -> model dtype
-  reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p.tn) + ((int64_t)bh * p.ntp + j) * 128)[lane] = out;
+  // a kept row whose unit-norm form holds NaN / inf (zero norm, non-finite key): the pivot kernel then keeps torch.max's
+  // NaN rules in its inner loop; otherwise every similarity of the head is finite and the loop is a plain strict '>'
+  if (lane == 0 && (!(n2 < INFINITY) || !(n > 0.f))) atomicOr(p.kept_bad + bh, 1);
+  uint16_t* dst = reinterpret_cast<uint16_t*>(p.tn) + ((int64_t)bh * p.ntp + j) * D + lane * EPL;
+  if constexpr (EPL == 1) dst[0] = Elem<T>::from_f32(x[0] / n);                     // k / norm -> model dtype
+  else if constexpr (EPL == 2) *reinterpret_cast<uint32_t*>(dst) = round_pack2<T>(x[0] / n, x[1] / n);
+  else *reinterpret_cast<uint2*>(dst) = make_uint2(round_pack2<T>(x[0] / n, x[1] / n), round_pack2<T>(x[2] / n, x[3] / n));
 }
 
 // ---- 4. pivot: for every dropped row the kept row with the largest cosine similarity (first maximum) ----
 // One wave = 16 dropped rows (MFMA A operand, unit-normalised in registers); the kept rows stream through LDS in tiles
 // of MP_TN targets as B operands; a workgroup walks MP_ITER row groups against the staged tile before the next tile.
-constexpr int MP_TN = 144;                // kept rows per LDS tile (39 KB): budget 128 + window 8 in ONE tile
 constexpr int MP_ROWS = 64;               // dropped rows per workgroup pass (4 waves x 16)
-constexpr int MP_ITER = 4;                // passes per workgroup: 256 dropped rows per workgroup
-constexpr int MP_TROW = 136;              // LDS row stride in elements (272 B: the 16 rows of a B fragment hit different banks)
+template <int KS> struct MergeShape {
+  static constexpr int D = KS * 32;
+  static constexpr int TN = KS == 8 ? 80 : 144;      // kept rows per LDS tile (<= 42 KB; a multiple of the 16 rows of a B fragment): budget 128 + window 8 in ONE tile at D <= 128
+  static constexpr int ITER = KS == 8 ? 2 : 4;       // passes per workgroup (64 dropped rows each): A operands = ITER x KS x 4 registers
+  static constexpr int TROW = D + 8;                 // LDS row stride in elements (+16 B: the 16 rows of a B fragment hit different banks)
+};
 
-template <typename T>
-__global__ __launch_bounds__(256) void merge_pivot_kernel(MergeParams p) {
+template <typename T, int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void merge_pivot_kernel(MergeParams p) {
+  using Sh = MergeShape<KS>;
+  constexpr int D = Sh::D, MP_TN = Sh::TN, MP_ITER = Sh::ITER, MP_TROW = Sh::TROW, CPR = D / 8;   // CPR: 16-B chunks per row
   __shared__ __attribute__((aligned(16))) uint16_t tile[MP_TN * MP_TROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -104,36 +154,38 @@ __global__ __launch_bounds__(256) void merge_pivot_kernel(MergeParams p) {
   if (row_wg >= n) return;
   const int nt = p.k + p.w;
   const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
-  const uint16_t* tn = reinterpret_cast<const uint16_t*>(p.tn) + (int64_t)bh * p.ntp * 128;
+  const uint16_t* tn = reinterpret_cast<const uint16_t*>(p.tn) + (int64_t)bh * p.ntp * D;
 
   // A operands of this wave's MP_ITER row groups: row li of group it = dropped row row_wg + it*64 + wave*16 + li.
-  // All 16 row loads of a lane are issued before any of them is used (one round trip instead of four).
-  u32x4 af[MP_ITER][4];
+  // All row loads of a lane are issued before any of them is used (one round trip instead of MP_ITER).
+  u32x4 af[MP_ITER][KS];
 #pragma unroll
   for (int it = 0; it < MP_ITER; ++it) {
     int r = row_wg + it * MP_ROWS + wave * 16 + li;
     r = r < n ? r : n - 1;                                               // clamp: rows past n are never written
     const uint16_t* row = kbase + (int64_t)p.drop[r] * p.ks_s + lg * 8;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) af[it][kk] = *reinterpret_cast<const u32x4*>(row + kk * 32);
+    for (int kk = 0; kk < KS; ++kk) af[it][kk] = *reinterpret_cast<const u32x4*>(row + kk * 32);
   }
+  bool bad_row = false;
 #pragma unroll
   for (int it = 0; it < MP_ITER; ++it) {
-    float xs[32];
+    float xs[KS * 8];
     float n2 = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < KS; ++kk) {
       U4 u;
       u.v = make_uint4(af[it][kk].x, af[it][kk].y, af[it][kk].z, af[it][kk].w);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { xs[kk * 8 + e] = Elem<T>::to_f32(u.h[e]); n2 += xs[kk * 8 + e] * xs[kk * 8 + e]; }
     }
-    n2 += __shfl_xor(n2, 16, 64);                                         // the row's 128 elements sit in 4 lanes (lg)
+    n2 += __shfl_xor(n2, 16, 64);                                         // the row's D elements sit in 4 lanes (lg)
     n2 += __shfl_xor(n2, 32, 64);
     const float nr = Elem<T>::to_f32(Elem<T>::from_f32(sqrtf(n2)));
+    bad_row |= !(n2 < INFINITY) || !(nr > 0.f);                           // the unit-norm row holds NaN / inf
     const float rn = 1.0f / nr;                                           // one division per row; div_const = correctly rounded x / nr
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < KS; ++kk) {
       u32x4 a;
       a.x = round_pack2<T>(div_const(xs[kk * 8 + 0], nr, rn), div_const(xs[kk * 8 + 1], nr, rn));
       a.y = round_pack2<T>(div_const(xs[kk * 8 + 2], nr, rn), div_const(xs[kk * 8 + 3], nr, rn));
@@ -142,174 +194,270 @@ __global__ __launch_bounds__(256) void merge_pivot_kernel(MergeParams p) {
       af[it][kk] = a;
     }
   }
-  // running best per (row group, accumulator register): lane holds rows 4*lg + r, column li of every 16-target tile
-  float bestv[MP_ITER][4];
-  int besti[MP_ITER][4];
+  // Running best per (row group, accumulator register): lane holds rows 4*lg + r, column li of every 16-target tile.
+  // A similarity in the model dtype is 16 bits, so (order-preserving key of the value) << 16 | (0xffff - kept-row number)
+  // is ONE unsigned word whose maximum is torch.max's answer (:151): the larger value, ties to the FIRST column; a NaN
+  // similarity (zero-norm row: 0/0 at :146) gets the largest key, so it ranks above everything and the first NaN wins, as
+  // torch.max propagates it.  One v_max_u32 per similarity instead of compare + two selects, half the registers.
+  uint32_t bestk[MP_ITER][4];
 #pragma unroll
   for (int it = 0; it < MP_ITER; ++it)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { bestv[it][r] = -INFINITY; besti[it][r] = 0x7fffffff; }
+    for (int r = 0; r < 4; ++r) bestk[it][r] = 0u;
 
+  // NaN similarities can only come from a unit-norm row that is not finite: without one in reach (the usual case) the
+  // NaN canonicalisation is skipped - the loop is bound by its vector instructions per similarity
+  const bool exact = p.kept_bad[bh] != 0 || __ballot(bad_row) != 0ull;     // wave-uniform
   for (int t0 = 0; t0 < nt; t0 += MP_TN) {
     const int tcnt = min(MP_TN, nt - t0);
     __syncthreads();
-    for (int c = tid; c < MP_TN * 16; c += 256) {                         // 16-B chunks; rows past tcnt are zero
-      const int rr = c >> 4;
+    for (int c = tid; c < MP_TN * CPR; c += 256) {                        // 16-B chunks; rows past tcnt are zero
+      const int rr = c / CPR, ch = c - rr * CPR;
       uint4 val = make_uint4(0, 0, 0, 0);
-      if (rr < tcnt) val = reinterpret_cast<const uint4*>(tn + (int64_t)(t0 + rr) * 128)[c & 15];
-      *reinterpret_cast<uint4*>(tile + rr * MP_TROW + (c & 15) * 8) = val;
+      if (rr < tcnt) val = reinterpret_cast<const uint4*>(tn + (int64_t)(t0 + rr) * D)[ch];
+      *reinterpret_cast<uint4*>(tile + rr * MP_TROW + ch * 8) = val;
     }
     __syncthreads();
     for (int n16 = 0; n16 * 16 < tcnt; ++n16) {
-      u32x4 bf[4];
+      u32x4 bf[KS];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) bf[kk] = *reinterpret_cast<const u32x4*>(tile + (n16 * 16 + li) * MP_TROW + kk * 32 + lg * 8);
+      for (int kk = 0; kk < KS; ++kk) bf[kk] = *reinterpret_cast<const u32x4*>(tile + (n16 * 16 + li) * MP_TROW + kk * 32 + lg * 8);
       const int col = t0 + n16 * 16 + li;
+      const uint32_t colkey = col < t0 + tcnt ? 0xffffu - (uint32_t)col : 0xffffffffu;   // all ones: a column past the tile (masked below)
 #pragma unroll
       for (int it = 0; it < MP_ITER; ++it) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(af[it][kk], bf[kk], acc);
+        for (int kk = 0; kk < KS; ++kk) acc = Mfma<T>::run(af[it][kk], bf[kk], acc);
+        uint32_t pk[2] = {round_pack2<T>(acc[0], acc[1]), round_pack2<T>(acc[2], acc[3])};   // similarities in the model dtype (:150)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sv = Elem<T>::to_f32(Elem<T>::from_f32(acc[r]));    // similarity in the model dtype (:150)
-          // strict >: first maximum.  A NaN similarity (zero-norm row: 0/0 at :146) ranks above everything and the FIRST
-          // NaN wins, as torch.max propagates it (:151)
-          const float bv = bestv[it][r];
-          if (col < nt && (sv > bv || (sv != sv && bv == bv))) { bestv[it][r] = sv; besti[it][r] = col; }
+        for (int h2 = 0; h2 < 2; ++h2) {
+          // both halves at once: sign-magnitude -> unsigned order (negative: all bits flipped, else the sign bit set)
+          const uint32_t neg = (pk[h2] >> 15) & 0x00010001u;
+          uint32_t m = pk[h2] ^ ((neg * 0xffffu) | 0x80008000u);
+          if (exact) {
+            if (Elem<T>::is_nan((uint16_t)(pk[h2] & 0xffffu))) m |= 0x0000ffffu;
+            if (Elem<T>::is_nan((uint16_t)(pk[h2] >> 16))) m |= 0xffff0000u;
+          }
+          const uint32_t k0 = (m << 16) | colkey, k1 = (m & 0xffff0000u) | colkey;
+          if (colkey != 0xffffffffu) {
+            bestk[it][2 * h2] = max(bestk[it][2 * h2], k0);
+            bestk[it][2 * h2 + 1] = max(bestk[it][2 * h2 + 1], k1);
+          }
         }
       }
     }
   }
-  // first maximum across the 16 columns (lanes of one lg group): larger value, ties to the smaller kept-row number
+  // first maximum across the 16 columns (lanes of one lg group): the largest key
 #pragma unroll
   for (int it = 0; it < MP_ITER; ++it) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = bestv[it][r];
-      int ix = besti[it][r];
+      uint32_t kx = bestk[it][r];
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        const float v2 = __shfl_xor(v, o, 64);
-        const int i2 = __shfl_xor(ix, o, 64);
-        const bool n1 = v != v, n2 = v2 != v2;
-        if ((n2 && !n1) || (!n1 && !n2 && v2 > v) || ((n1 == n2) && (n1 || v2 == v) && i2 < ix)) { v = v2; ix = i2; }
-      }
+      for (int o = 1; o < 16; o <<= 1) kx = max(kx, (uint32_t)__shfl_xor((int)kx, o, 64));
       const int row = row_wg + it * MP_ROWS + wave * 16 + lg * 4 + r;
-      if (li == 0 && row < n) p.pivot[(int64_t)bh * p.S + row] = ix;
+      if (li == 0 && row < n) p.pivot[(int64_t)bh * p.S + row] = (int32_t)(0xffffu - (kx & 0xffffu));
     }
   }
 }
 
-// ---- 5. scatter-mean: kept row j collects, in ascending order, the dropped rows that chose it ----
-// Workgroup = one kept row of one (b,h): threads 0..127 = the 128 elements of the KEY row, 128..255 of the VALUE row.
-// The ordered source list is built without barriers: wave w scans the w-th quarter of a chunk of MS_CHUNK pivots (8 loads in
-// flight per lane, ballot + mbcnt compaction into its own LDS segment); the four segments in wave order are the ascending
-// list.  The walk keeps two batches of 16 row loads in flight (the next batch is issued before the current one is consumed):
-// the fp32 accumulation order is the list order, whatever the latency of a row.
-constexpr int MS_CHUNK = 8192;            // pivots per pass (2048 per wave)
-constexpr int MS_SEG = MS_CHUNK / 4;      // LDS list segment per wave
+// ---- 5. bucket: per (b,h) the dropped rows grouped by the kept row they chose (counting sort over the pivots) ----
+// One workgroup of 1024 threads per head: LDS histogram over a range of MB_RANGE kept rows, exclusive scan (written out as
+// bstart[bh][j]), placement through LDS cursors.  blist holds the dropped POSITIONS; within a group the order is whatever
+// the atomics produced - the scatter kernel orders every group itself.  More than MB_RANGE kept rows: one pass per range.
+constexpr int MB_RANGE = 8192;
+
+__global__ __launch_bounds__(1024) void merge_bucket_kernel(MergeParams p) {
+  __shared__ int32_t cnt[MB_RANGE];
+  __shared__ int32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x;
+  const int n = *p.ndrop, nt = p.k + p.w;
+  const int32_t* piv = p.pivot + (int64_t)bh * p.S;
+  int32_t* list = p.blist + (int64_t)bh * p.S;
+  int32_t* start = p.bstart + (int64_t)bh * (nt + 1);
+  int base = 0;                                                           // rows placed by the earlier ranges
+  for (int lo = 0; lo < nt; lo += MB_RANGE) {
+    const int hi = min(nt, lo + MB_RANGE);
+    for (int j = tid; j < MB_RANGE; j += 1024) cnt[j] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 8 * 1024) {                             // 8 loads in flight per thread (a plain loop pays one round trip per element)
+      int pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024 + tid; pv[u] = piv[i < n ? i : n - 1]; if (i >= n) pv[u] = -1; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (pv[u] >= lo && pv[u] < hi) atomicAdd(&cnt[pv[u] - lo], 1);
+    }
+    __syncthreads();
+    int c[8], sum = 0;                                                    // 8 consecutive kept rows per thread
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { c[e] = cnt[tid * 8 + e]; sum += c[e]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) { const int t2 = wsum[w2]; total += t2; woff += w2 < wave ? t2 : 0; }
+    int run = base + woff + incl - sum;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = lo + tid * 8 + e;
+      if (j < hi) start[j] = run;
+      cnt[tid * 8 + e] = run;                                             // the group's cursor
+      run += c[e];
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 8 * 1024) {
+      int pv[8], pos[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 1024 + tid;
+        pv[u] = piv[i < n ? i : n - 1];
+        pos[u] = p.drop[i < n ? i : n - 1];
+        if (i >= n) pv[u] = -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (pv[u] >= lo && pv[u] < hi) list[atomicAdd(&cnt[pv[u] - lo], 1)] = pos[u];
+    }
+    base += total;
+    __syncthreads();
+  }
+  if (tid == 0) start[nt] = base;
+}
+
+// ---- 6. scatter-mean: kept row j collects, in ascending order, the dropped rows that chose it ----
+// Workgroup = one kept row of one (b,h): threads 0..D-1 = the elements of the KEY row, D..2D-1 of the VALUE row.  The group
+// arrives unordered; the reference accumulates in ascending position (fp32, scatter_reduce walks the source in order), so
+// the positions are set as bits of an LDS bitmap over [0, S) and read back in order: a popcount prefix gives every set bit
+// its rank, MS_CAP ranks at a time become the list of a walk.  The walk keeps two batches of row loads in flight (the next
+// batch is issued before the current one is consumed): the accumulation order is the list order, whatever the latency.
+constexpr int MS_CAP = 2048;              // list entries per pass
 constexpr int MS_B = 32;                  // rows per batch of the walk (all in flight together)
 
-template <typename T>
-__global__ __launch_bounds__(256) void merge_scatter_kernel(MergeParams p) {
-  __shared__ int32_t list[MS_CHUNK];
-  __shared__ uint32_t wcount[4];
+template <typename T, int KS>
+__global__ __launch_bounds__(KS * 64) void merge_scatter_kernel(MergeParams p) {
+  constexpr int D = KS * 32, NTH = 2 * D, NW = NTH / 64;
+  extern __shared__ __attribute__((aligned(16))) uint32_t ms_bitmap[];    // [(S + 31) / 32]
+  __shared__ int32_t lst[MS_CAP];
+  __shared__ int32_t wsum[NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int d = tid & 127, is_v = tid >> 7;
+  const int d = tid % D, is_v = tid / D;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
   const int j = blockIdx.x;
-  const int n = *p.ndrop;
+  const int nt = p.k + p.w;
   const int32_t* idx_row = p.idx + (int64_t)bh * p.idx_stride;
-  const int32_t* piv = p.pivot + (int64_t)bh * p.S;
+  const int32_t* start = p.bstart + (int64_t)bh * (nt + 1);
+  const int beg = start[j], m = start[j + 1] - beg;
+  const int32_t* group = p.blist + (int64_t)bh * p.S + beg;
   const uint16_t* base = is_v ? reinterpret_cast<const uint16_t*>(p.vptr) + (int64_t)b * p.vs_b + (int64_t)hk * p.vs_h
                               : reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const int64_t sstride = is_v ? p.vs_s : p.ks_s;
   const int tpos = is_v ? val_target_pos(p, idx_row, j) : key_target_pos(p, idx_row, j);
   const float t = Elem<T>::to_f32(base[(int64_t)tpos * sstride + d]);     // the kept row BEFORE merging (gather at :157/:160)
   float acc = t;                                                          // include_self
-  int cnt = 1;
-  for (int c0 = 0; c0 < n; c0 += MS_CHUNK) {
-    __syncthreads();                                                      // the previous chunk's list has been walked
-    // wave-private scan of [c0 + wave*MS_SEG, +MS_SEG): 8 pivot loads in flight per lane, no barrier inside
-    uint32_t run = 0;
-    const int w0 = c0 + wave * MS_SEG;
-    for (int s0 = w0; s0 < min(n, w0 + MS_SEG); s0 += 8 * 64) {
-      int pv[8], dr[8];      // pivots AND drop positions up front: a drop[] load behind a hit would stall every hit for a round trip
+  if (m > 0) {                                                            // workgroup-uniform
+    const int nw = (p.S + 31) >> 5;
+    for (int wd = tid; wd < nw; wd += NTH) ms_bitmap[wd] = 0u;
+    __syncthreads();
+    for (int e = tid; e < m; e += NTH) { const int s = group[e]; atomicOr(&ms_bitmap[s >> 5], 1u << (s & 31)); }
+    __syncthreads();
+    // thread t owns the words [t*wpt, (t+1)*wpt): rank of its first set bit = exclusive prefix of the popcounts
+    const int wpt = (nw + NTH - 1) / NTH;
+    const int w0 = min(nw, tid * wpt), w1 = min(nw, w0 + wpt);
+    int pc = 0;
+    for (int wd = w0; wd < w1; ++wd) pc += __popc(ms_bitmap[wd]);
+    int incl = pc;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = s0 + u * 64 + lane; pv[u] = piv[i < n ? i : n - 1]; dr[u] = p.drop[i < n ? i : n - 1]; }
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = s0 + u * 64 + lane;
-        const bool hit = i < n && i < w0 + MS_SEG && pv[u] == j;
-        const uint64_t bal = __ballot(hit);
-        if (bal != 0ull) {
-          const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          if (hit) list[wave * MS_SEG + run + before] = dr[u];
-          run += (uint32_t)__popcll(bal);
+    for (int w2 = 0; w2 < NW; ++w2) woff += w2 < wave ? wsum[w2] : 0;
+    const int first = woff + incl - pc;
+    for (int pass0 = 0; pass0 < m; pass0 += MS_CAP) {
+      int r = first;
+      for (int wd = w0; wd < w1 && r < pass0 + MS_CAP; ++wd) {
+        uint32_t bits = ms_bitmap[wd];
+        const int c = __popc(bits);
+        if (r + c <= pass0) { r += c; continue; }
+        while (bits) {
+          const int bpos = __builtin_ctz(bits);
+          bits &= bits - 1;
+          if (r >= pass0 && r < pass0 + MS_CAP) lst[r - pass0] = wd * 32 + bpos;
+          ++r;
         }
       }
-    }
-    if (lane == 0) wcount[wave] = run;
-    __syncthreads();
-    // ascending walk over the four segments as ONE list (entry l lives in segment sg at l - first[sg]); batches of MS_B rows,
-    // the next batch in flight while the current one is consumed: one exposed row latency per pass, not one per segment
-    const uint32_t f1 = wcount[0], f2 = f1 + wcount[1], f3 = f2 + wcount[2], m = f3 + wcount[3];
-    auto entry = [&](uint32_t l) -> int32_t {
-      l = l < m ? l : (m ? m - 1 : 0u);
-      const uint32_t sg = (l >= f1) + (l >= f2) + (l >= f3);
-      const uint32_t first = sg == 0 ? 0u : (sg == 1 ? f1 : (sg == 2 ? f2 : f3));
-      return list[sg * MS_SEG + (l - first)];
-    };
-    // Every lane would otherwise repeat the (wave-uniform) list look-up and 64-bit address arithmetic for every row: ~15
-    // vector instructions per row and lane made this walk VALU-bound.  Instead each lane looks up ONE entry of a block of 64
-    // rows; the row numbers then reach the scalar unit through v_readlane and the loads use a scalar base.
-    for (uint32_t l64 = 0; l64 < m; l64 += 64) {
-      const int myrow = entry(l64 + (uint32_t)lane);
-      const uint32_t left = m - l64 < 64u ? m - l64 : 64u;
-      for (uint32_t b0 = 0; b0 < left; b0 += MS_B) {
-        uint16_t x[MS_B];
+      __syncthreads();
+      const uint32_t mm = (uint32_t)min(MS_CAP, m - pass0);
+      // Every lane would otherwise repeat the (wave-uniform) list look-up and 64-bit address arithmetic for every row: ~15
+      // vector instructions per row and lane made this walk VALU-bound.  Instead each lane looks up ONE entry of a block of 64
+      // rows; the row numbers then reach the scalar unit through v_readlane and the loads use a scalar base.
+      for (uint32_t l64 = 0; l64 < mm; l64 += 64) {
+        const int myrow = lst[l64 + (uint32_t)lane < mm ? l64 + (uint32_t)lane : mm - 1];
+        const uint32_t left = mm - l64 < 64u ? mm - l64 : 64u;
+        for (uint32_t b0 = 0; b0 < left; b0 += MS_B) {
+          uint16_t x[MS_B];
 #pragma unroll
-        for (int u = 0; u < MS_B; ++u) {
-          const int r = __builtin_amdgcn_readlane(myrow, (int)(b0 + u < 64u ? b0 + u : 63u));   // rows past `left` repeat the last entry (masked below)
-          x[u] = base[(int64_t)r * sstride + d];
-        }
+          for (int u = 0; u < MS_B; ++u) {
+            const int r2 = __builtin_amdgcn_readlane(myrow, (int)(b0 + u < 64u ? b0 + u : 63u));   // rows past `left` repeat the last entry (masked below)
+            x[u] = base[(int64_t)r2 * sstride + d];
+          }
 #pragma unroll
-        for (int u = 0; u < MS_B; ++u) {
-          if (b0 + u < left) {
-            const float half = Elem<T>::to_f32(Elem<T>::from_f32(Elem<T>::to_f32(x[u]) + t)) * 0.5f;   // (x + t) -> dtype, / 2 (:158)
-            acc = __fadd_rn(acc, Elem<T>::to_f32(Elem<T>::from_f32(half)));
+          for (int u = 0; u < MS_B; ++u) {
+            if (b0 + u < left) {
+              const float half = Elem<T>::to_f32(Elem<T>::from_f32(Elem<T>::to_f32(x[u]) + t)) * 0.5f;   // (x + t) -> dtype, / 2 (:158)
+              acc = __fadd_rn(acc, Elem<T>::to_f32(Elem<T>::from_f32(half)));
+            }
           }
         }
       }
+      __syncthreads();                                                    // the list has been walked
     }
-    cnt += (int)m;
   }
+  const int cnt = 1 + m;
   const float sum_q = Elem<T>::to_f32(Elem<T>::from_f32(acc));            // the scattered SUM in the model dtype
   const float cnt_q = Elem<T>::to_f32(Elem<T>::from_f32((float)cnt));     // the count in the model dtype (rounds above 256 / 2048)
-  uint16_t* out = reinterpret_cast<uint16_t*>(is_v ? p.v_out : p.k_out) + ((int64_t)bh * (p.k + p.w) + j) * 128 + d;
+  uint16_t* out = reinterpret_cast<uint16_t*>(is_v ? p.v_out : p.k_out) + ((int64_t)bh * nt + j) * D + d;
   *out = Elem<T>::from_f32(sum_q / cnt_q);
 }
 
+template <typename T, int KS>
+hipError_t launch_merge_t(const MergeParams& p, hipStream_t st) {
+  using Sh = MergeShape<KS>;
+  const int nt = p.k + p.w;
+  const dim3 gt((nt + 3) / 4, p.B * p.H), gp((p.S + MP_ROWS * Sh::ITER - 1) / (MP_ROWS * Sh::ITER), p.B * p.H), gs(nt, p.B * p.H);
+  const size_t bitmap_bytes = (size_t)((p.S + 31) / 32) * 4;
+  hipLaunchKernelGGL((merge_targets_kernel<T, KS>), gt, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((merge_pivot_kernel<T, KS>), gp, dim3(256), 0, st, p);
+  hipLaunchKernelGGL(merge_bucket_kernel, dim3(p.B * p.H), dim3(1024), 0, st, p);
+  hipLaunchKernelGGL((merge_scatter_kernel<T, KS>), gs, dim3(KS * 64), bitmap_bytes, st, p);
+  return hipGetLastError();
+}
+
+size_t merge_max_seq() { return 49152u * 8u; }    // the scatter kernel's position bitmap (one bit per position): 48 KB of dynamic LDS
+
 hipError_t launch_merge(int dtype, const MergeParams& p, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(p.mask, 0, (size_t)p.S, st);
+  // the union bitmap and, directly behind it, the per-head flags of the targets kernel
+  hipError_t e = hipMemsetAsync(p.mask, 0, (size_t)(reinterpret_cast<char*>(p.kept_bad) - reinterpret_cast<char*>(p.mask)) + (size_t)p.B * p.H * 4, st);
   if (e != hipSuccess) return e;
   const int64_t total = (int64_t)p.B * p.H * p.k;
   const int mb = (int)std::min<int64_t>((total + 255) / 256, 1024);
   hipLaunchKernelGGL(merge_mark_kernel, dim3(mb), dim3(256), 0, st, p);
   hipLaunchKernelGGL(merge_droplist_kernel, dim3(1), dim3(1024), 0, st, p);
-  const int nt = p.k + p.w;
-  const dim3 gt((nt + 3) / 4, p.B * p.H), gp((p.S + MP_ROWS * MP_ITER - 1) / (MP_ROWS * MP_ITER), p.B * p.H), gs(nt, p.B * p.H);
   if (dtype == 0) {
-    hipLaunchKernelGGL(merge_targets_kernel<BF16>, gt, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(merge_pivot_kernel<BF16>, gp, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(merge_scatter_kernel<BF16>, gs, dim3(256), 0, st, p);
-  } else {
-    hipLaunchKernelGGL(merge_targets_kernel<F16>, gt, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(merge_pivot_kernel<F16>, gp, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(merge_scatter_kernel<F16>, gs, dim3(256), 0, st, p);
+    if (p.D == 64) return launch_merge_t<BF16, 2>(p, st);
+    if (p.D == 256) return launch_merge_t<BF16, 8>(p, st);
+    return launch_merge_t<BF16, 4>(p, st);
   }
-  return hipGetLastError();
+  if (p.D == 64) return launch_merge_t<F16, 2>(p, st);
+  if (p.D == 256) return launch_merge_t<F16, 8>(p, st);
+  return launch_merge_t<F16, 4>(p, st);
 }
 
 }  // namespace pkv
