@@ -54,8 +54,7 @@ enum pkv_scale { PKV_SCALE_DIV = 0, PKV_SCALE_RCP = 1 };
 
 typedef struct pkv_desc {
   int32_t dtype;        /* pkv_dtype of q,k,v and of every score buffer */
-  int32_t B, H, S, D;   /* H = number of query heads; D = 128 (all entry points) or 64 / 256 (not
-                           pkv_merge_compact: PKV_ERR_UNSUPPORTED) */
+  int32_t B, H, S, D;   /* H = number of query heads; D = 64, 128 or 256 (all entry points) */
   int32_t kv_group;     /* 1: k,v have H heads (post-repeat_kv, the reference contract).
                            g>1: k,v have H/g heads (un-expanded GQA); head h reads kv head h/g */
   int64_t q_stride[3];  /* element strides of q for b,h,s */
@@ -135,7 +134,8 @@ int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int
  * kept rows become the scatter-mean of what reached them (:158-162).  As in the reference k_out is ordered
  * [window, selected] (:146) and v_out [selected, window] (:148), and the value merge uses the key order's pivot numbers.
  * idx: int32 [B*H][idx_stride] (d->topk = k entries per row, from pkv_select / pkv_topk).  Outputs [B,H,k+w,D] contiguous.
- * ws: pkv_merge_workspace_bytes(d), 16-B aligned.  Rounding points: oracle/pkv_oracle.py merge_kv_explicit. */
+ * ws: pkv_merge_workspace_bytes(d), 16-B aligned.  Rounding points: oracle/pkv_oracle.py merge_kv_explicit.
+ * bf16 / fp16, D = 64 / 128 / 256; S <= 393 216 and k + window <= 65 535 (PKV_ERR_UNSUPPORTED beyond, and for fp32). */
 size_t pkv_merge_workspace_bytes(const pkv_desc* d);
 int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx, int64_t idx_stride,
                       void* k_out, void* v_out, void* ws, size_t ws_bytes, pkv_stream_t stream);

@@ -30,7 +30,7 @@ int logits_nt() { static int t = env_int("PKV_LOGITS_NT", 0); return t; }
 // pipelined logits kernel (logits2_kernel): 1 = use it when the column count allows, 0 = one-tile-per-workgroup kernel
 int logits_v2() { static int t = env_int("PKV_LOGITS_V2", 1); return t; }
 int logits_v2_nt() { static int t = env_int("PKV_LOGITS_NT", 1); return t; }
-int logits_v2_wgs() { static int t = env_int("PKV_LOGITS_V2_WGS", 0); return t; }   // target workgroup count, 0 = 8 per CU
+int logits_v2_wgs() { static int t = env_int("PKV_LOGITS_V2_WGS", 0); return t; }   // target workgroup count, 0 = by column count (below)
 int logits_fexp() { static int t = env_int("PKV_LOGITS_FEXP", 1); return t; }       // hardware exp2 in the partial statistics
 int logits_store() { static int t = env_int("PKV_LOGITS_ST", 2); return t; }        // 0 plain, 1 nontemporal, 2 write-through
 #ifdef PKV_DEBUG
@@ -94,7 +94,7 @@ struct ProfScope {
 int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true, bool f32_ok = false) {
   if (!d) return PKV_ERR_NULL;
   if (d->dtype != PKV_BF16 && d->dtype != PKV_F16 && d->dtype != PKV_F32) return PKV_ERR_DTYPE;
-  if (d->D != 64 && d->D != 128 && d->D != 256) return PKV_ERR_SHAPE;      // the merge: 128 only (checked there)
+  if (d->D != 64 && d->D != 128 && d->D != 256) return PKV_ERR_SHAPE;
   if (d->dtype == PKV_F32 && (!f32_ok || d->D == 256)) return PKV_ERR_UNSUPPORTED;
   if (d->B < 1 || d->H < 1 || d->S < 2) return PKV_ERR_SHAPE;
   if (d->kv_group < 1 || d->H % d->kv_group) return PKV_ERR_SHAPE;
@@ -192,7 +192,9 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     // {1, 2, 3, 4, 8 stages}: 1 is the fastest at B = 1 (45.1-46.0 us against 45.7-48.6 us for 4 stages in the same
     // sessions; 2 and 3 stages are the slowest) and at B = 8 (350 vs 353 us): the in-workgroup pipeline only pays when few
     // workgroups share a CU.  More columns per stage (un-expanded GQA K, C = 32): 4 workgroups per CU with 2..8 stages each
-    // (one stage per workgroup costs +4 us there).
+    // (one stage per workgroup costs +4 us there).  Round 3, after the logits stores moved one stage back (pkv_score.hip):
+    // same ranking - C = 8: 44.3 us at 1 stage, 46.2 / 45.6 / 46.4 / 47.3 at 2 / 4 / 8 / 16; C = 32: 16.8 us at 2 stages
+    // (1024 workgroups), 17.2 at 3, 17.3 at 4, 20.1 at 1 (profiles/r03/ab/defer_stores_ab.txt, one_stage_lds_direct_ab.txt).
     const int64_t target = logits_v2_wgs() > 0 ? logits_v2_wgs() : (C > 8 ? (int64_t)4 * cus : total);
     int nst = (int)((total + target - 1) / target);
     nst = std::max(1, std::min(nst, std::min(sph, 64)));

@@ -142,7 +142,7 @@ template <int KS> struct MergeShape {
 };
 
 template <typename T, int KS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void merge_pivot_kernel(MergeParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS == 8 ? 3 : 4))) void merge_pivot_kernel(MergeParams p) {
   using Sh = MergeShape<KS>;
   constexpr int D = Sh::D, MP_TN = Sh::TN, MP_ITER = Sh::ITER, MP_TROW = Sh::TROW, CPR = D / 8;   // CPR: 16-B chunks per row
   __shared__ __attribute__((aligned(16))) uint16_t tile[MP_TN * MP_TROW];
