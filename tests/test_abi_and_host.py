@@ -251,6 +251,8 @@ def test_abi_argument_fuzz_never_crashes(P):
     """3000 random descriptors / pointers through the entry points that validate before they launch: every call returns a
     documented status (or a size), nothing aborts, throws or reads through a null pointer - also without a GPU."""
     import random
+    if torch.cuda.is_available():
+        pytest.skip("descriptors that validate would launch on the fake pointers: a host-only test")
     N = P._native
     rnd = random.Random(1)
     seen = set()

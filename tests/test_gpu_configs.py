@@ -445,6 +445,23 @@ def test_merge_many_kept_rows_and_one_huge_group(P):
     assert torch.equal(km.cpu()[:, :, j], kr[:, :, j])
 
 
+def test_merge_long_sequence_more_than_8192_kept_rows(P):
+    """S = 40 001 and 8 208 kept rows per head: the bucket kernel's LDS histogram takes two ranges of kept rows, the scatter
+    kernel's position bitmap several words per thread, the pivot kernel 57 LDS tiles.  D = 64 keeps the oracle's
+    (dropped x kept) similarity matrix at 0.5 GB."""
+    B, H, S, w, k, D = 1, 1, 40001, 8, 8200, 64
+    _, K, V = make_qkv(B, H, S, D, "bf16", "lattice", 7900)
+    K[:, :, ::3] = (K[:, :, ::3].float() * 0.5).to(K.dtype)
+    gen = torch.Generator().manual_seed(9)
+    idx = torch.randperm(S - w, generator=gen)[:k][None, None, :]
+    kr, vr = O.merge_kv(K, V, idx, w, "pivot")
+    km, vm = P.ops.merge_compact(K.to(DEV), V.to(DEV), idx.to(DEV).int(), w)
+    fk, _ = _merge_close(km.cpu(), kr)
+    fv, _ = _merge_close(vm.cpu(), vr)
+    _report("merge_long_sequence", dict(k_mismatch_frac=fk, v_mismatch_frac=fv))
+    assert fk <= 0.002 and fv <= 0.002, (fk, fv)
+
+
 # ----------------------------------------------------------------------------------------- head sizes other than 128
 @pytest.mark.parametrize("D", [64, 256])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])

@@ -229,6 +229,24 @@ if tt:
     for k, v in tt.items():
         lines.append("| %s | %s | %s | %s |" % (k, v["C"], v["total"], v["stamps_rel"]))
     lines.append("")
+mb, ms_ = os.path.join(G, "merge_bench.json"), os.path.join(G, "merge_kernel_split.txt")
+if os.path.exists(mb) and os.path.getsize(mb):
+    shutil.copy(mb, os.path.join(P, "merge_bench.json"))
+    m = json.load(open(mb))
+    old = os.path.join(ROOT, "profiles", "r02", "merge_bench.json")
+    o = json.load(open(old)) if os.path.exists(old) else {}
+    lines += ["## LOOK-M merge (tools/merge_bench.py, H = 32, D = 128, bf16; ms per call)\n",
+              "| S, budget | update_kv plain | update_kv merge | merge alone | merge alone, round 2 | reference ops, eager on this GPU |", "|---|---|---|---|---|---|"]
+    for k_, v in m.items():
+        lines.append("| %s | %.4f | %.4f | %.4f | %s | %.3f |" % (k_, v["update_kv_plain_ms"], v["update_kv_merge_ms"], v["merge_only_ms"],
+                                                              ("%.4f" % o[k_]["merge_only_ms"]) if k_ in o else "-", v["reference_ops_eager_merge_ms"]))
+    lines.append("")
+    if os.path.exists(ms_):
+        shutil.copy(ms_, os.path.join(P, "merge_kernel_split.txt"))
+        lines += ["Per-kernel split (rocprofv3 --kernel-trace --stats -- python tools/merge_only.py S budget; `merge_kernel_split.txt`):\n", "```", open(ms_).read().strip(), "```", ""]
+abdir = os.path.join(P, "ab")
+if os.path.isdir(abdir):
+    lines += ["## Same-session A/B files of this round (`ab/`)\n"] + ["* `ab/%s`" % f_ for f_ in sorted(os.listdir(abdir))] + [""]
 sm = os.path.join(G, "smoke.log")
 if os.path.exists(sm):
     shutil.copy(sm, os.path.join(P, "smoke.log"))

@@ -41,5 +41,18 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIV
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_h2o_c -- python $R/tools/h2o_only.py 32768 > $O/pmc_h2o_c.log 2>&1
 fi
 cd $R
+# LOOK-M merge: wall time per call and the per-kernel split
+timeout 300 python tools/merge_bench.py > $O/merge_bench.json 2> $O/merge_bench.err
+for cfg in "32768 128" "32768 2048" "8192 2048"; do
+  tag=$(echo $cfg | tr ' ' '_')
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_merge_$tag -- python $R/tools/merge_only.py $cfg > /dev/null 2>&1)
+  f=$(find $O/prof_merge_$tag -name "*kernel_stats.csv" | head -1)
+  echo "== S, budget: $cfg"; [ -n "$f" ] && python - "$f" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if "merge" in r["Name"]:
+        print("%-60s calls %4s avg %9.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+done > $O/merge_kernel_split.txt 2>&1
 timeout 200 python tools/soak.py 60 > $O/soak.txt 2>&1; echo "soak exit $?" >> $O/soak.txt
 tail -4 $O/pytest.txt 2>/dev/null; tail -2 $O/soak.txt; head -c 400 $O/bench.json; echo; tail -2 $O/bench.err; tail -1 $O/parity_sweep.log
