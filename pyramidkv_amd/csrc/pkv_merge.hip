@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void merge_targets_kernel(MergeParams p) {
   for (int e = 0; e < EPL; ++e) { x[e] = Elem<T>::to_f32(raw[e]); sq += x[e] * x[e]; }
   const float n2 = wave_sum(sq);
   const float n = Elem<T>::to_f32(Elem<T>::from_f32(sqrtf(n2)));                    // torch.norm -> model dtype
-  // a kept row whose unit-norm form holds NaN / inf (zero norm, non-finite key): the pivot kernel then keeps torch.max's
-  // NaN rules in its inner loop; otherwise every similarity of the head is finite and the loop is a plain strict '>'
+  // a kept row whose unit-norm form holds NaN / inf (zero norm, non-finite key): the pivot kernel then canonicalises NaN
+  // similarities in its inner loop (torch.max's rules); otherwise every similarity of the head is finite and it skips that
   if (lane == 0 && (!(n2 < INFINITY) || !(n > 0.f))) atomicOr(p.kept_bad + bh, 1);
   uint16_t* dst = reinterpret_cast<uint16_t*>(p.tn) + ((int64_t)bh * p.ntp + j) * D + lane * EPL;
   if constexpr (EPL == 1) dst[0] = Elem<T>::from_f32(x[0] / n);                     // k / norm -> model dtype
