@@ -298,6 +298,22 @@ def test_merge_zero_norm_dropped_keys_follow_torch_max(P):
     assert np.array_equal(bits(km), bits(kr)) and np.array_equal(bits(vm), bits(vr))
 
 
+def test_merge_zero_norm_kept_key_follows_torch_max(P):
+    """A KEPT key row of zeros: its unit-norm form is NaN, so every dropped row's similarity to that column is NaN and
+    torch.max (:151) stops at the first NaN - all dropped rows of the head merge into the first such kept row.  Also a
+    non-finite dropped row next to it (its similarities are NaN everywhere: kept row 0).  The pivot kernel takes its NaN-aware
+    path only for heads / waves that can see such a row (flag from the targets kernel, ballot over the wave's rows)."""
+    B, H, S, w, k = 1, 3, 900, 8, 40
+    q, K, V = make_qkv(B, H, S, 128, "bf16", "lattice", 7350)
+    idx = (torch.arange(k)[None, None, :].repeat(B, H, 1) * 7 + 2)
+    K[:, 1, int(idx[0, 1, 5])] = 0                        # head 1: the 6th selected key (kept row w + 5) has zero norm
+    K[:, 2, 500] = 0                                      # head 2: a dropped zero row (500 is not 2 mod 7 below 282... not selected)
+    assert 500 not in idx[0, 2].tolist()
+    kr, vr = O.merge_kv(K, V, idx, w, "pivot")
+    km, vm = P.ops.merge_compact(K.to(DEV), V.to(DEV), idx.to(DEV).int(), w)
+    assert np.array_equal(bits(km), bits(kr)) and np.array_equal(bits(vm), bits(vr))
+
+
 def test_merge_golden_fixtures_and_clusters(P):
     """The REAL reference's merged K/V (tests/golden/*_merge.npz) vs the HIP clusters with merge='pivot': bit-identical on
     the tie-free fixtures (selection fully determined); on the others the clusters must equal the oracle's merge of the
