@@ -331,7 +331,7 @@ __global__ __launch_bounds__(1024) void merge_bucket_kernel(MergeParams p) {
 }
 
 // ---- 6. scatter-mean: kept row j collects, in ascending order, the dropped rows that chose it ----
-// Workgroup = one kept row of one (b,h): threads 0..D-1 = the elements of the KEY row, D..2D-1 of the VALUE row.  The group
+// Workgroup = one kept row of one (b,h): threads 0..D/2-1 = the KEY row (two adjacent elements each), D/2..D-1 the VALUE row.  The group
 // arrives unordered; the reference accumulates in ascending position (fp32, scatter_reduce walks the source in order), so
 // the positions are set as bits of an LDS bitmap over [0, S) and read back in order: a popcount prefix gives every set bit
 // its rank, MS_CAP ranks at a time become the list of a walk.  The walk keeps two batches of row loads in flight (the next
@@ -340,13 +340,13 @@ constexpr int MS_CAP = 2048;              // list entries per pass
 constexpr int MS_B = 32;                  // rows per batch of the walk (all in flight together)
 
 template <typename T, int KS>
-__global__ __launch_bounds__(KS * 64) void merge_scatter_kernel(MergeParams p) {
-  constexpr int D = KS * 32, NTH = 2 * D, NW = NTH / 64;
+__global__ __launch_bounds__(KS * 32) void merge_scatter_kernel(MergeParams p) {
+  constexpr int D = KS * 32, NTH = D, NW = NTH / 64;        // two adjacent elements per thread: D/2 threads per row, K then V
   extern __shared__ __attribute__((aligned(16))) uint32_t ms_bitmap[];    // [(S + 31) / 32]
   __shared__ int32_t lst[MS_CAP];
   __shared__ int32_t wsum[NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int d = tid % D, is_v = tid / D;
+  const int d = (tid % (D / 2)) * 2, is_v = tid / (D / 2);
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
   const int j = blockIdx.x;
   const int nt = p.k + p.w;
@@ -358,8 +358,9 @@ __global__ __launch_bounds__(KS * 64) void merge_scatter_kernel(MergeParams p) {
                               : reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const int64_t sstride = is_v ? p.vs_s : p.ks_s;
   const int tpos = is_v ? val_target_pos(p, idx_row, j) : key_target_pos(p, idx_row, j);
-  const float t = Elem<T>::to_f32(base[(int64_t)tpos * sstride + d]);     // the kept row BEFORE merging (gather at :157/:160)
-  float acc = t;                                                          // include_self
+  const uint32_t traw = *reinterpret_cast<const uint32_t*>(base + (int64_t)tpos * sstride + d);   // the kept row BEFORE merging (gather at :157/:160)
+  const pkv_f32x2 t = {Elem<T>::to_f32((uint16_t)(traw & 0xffffu)), Elem<T>::to_f32((uint16_t)(traw >> 16))};
+  pkv_f32x2 acc = t;                                                      // include_self
   if (m > 0) {                                                            // workgroup-uniform
     const int nw = (p.S + 31) >> 5;
     for (int wd = tid; wd < nw; wd += NTH) ms_bitmap[wd] = 0u;
@@ -402,17 +403,22 @@ __global__ __launch_bounds__(KS * 64) void merge_scatter_kernel(MergeParams p) {
         const int myrow = lst[l64 + (uint32_t)lane < mm ? l64 + (uint32_t)lane : mm - 1];
         const uint32_t left = mm - l64 < 64u ? mm - l64 : 64u;
         for (uint32_t b0 = 0; b0 < left; b0 += MS_B) {
-          uint16_t x[MS_B];
+          uint32_t x[MS_B];
 #pragma unroll
           for (int u = 0; u < MS_B; ++u) {
             const int r2 = __builtin_amdgcn_readlane(myrow, (int)(b0 + u < 64u ? b0 + u : 63u));   // rows past `left` repeat the last entry (masked below)
-            x[u] = base[(int64_t)r2 * sstride + d];
+            x[u] = *reinterpret_cast<const uint32_t*>(base + (int64_t)r2 * sstride + d);
           }
 #pragma unroll
           for (int u = 0; u < MS_B; ++u) {
             if (b0 + u < left) {
-              const float half = Elem<T>::to_f32(Elem<T>::from_f32(Elem<T>::to_f32(x[u]) + t)) * 0.5f;   // (x + t) -> dtype, / 2 (:158)
-              acc = __fadd_rn(acc, Elem<T>::to_f32(Elem<T>::from_f32(half)));
+              // two elements per packed fp32 instruction (IEEE per component, no contraction): (x + t) -> dtype, / 2 -> dtype (:158)
+              const pkv_f32x2 xv = {Elem<T>::to_f32((uint16_t)(x[u] & 0xffffu)), Elem<T>::to_f32((uint16_t)(x[u] >> 16))};
+              const pkv_f32x2 sm = xv + t;
+              const uint32_t r1 = round_pack2<T>(sm.x, sm.y);
+              const pkv_f32x2 hf = pkv_f32x2{Elem<T>::to_f32((uint16_t)(r1 & 0xffffu)), Elem<T>::to_f32((uint16_t)(r1 >> 16))} * pkv_f32x2{0.5f, 0.5f};
+              const uint32_t r2b = round_pack2<T>(hf.x, hf.y);
+              acc = acc + pkv_f32x2{Elem<T>::to_f32((uint16_t)(r2b & 0xffffu)), Elem<T>::to_f32((uint16_t)(r2b >> 16))};
             }
           }
         }
@@ -421,10 +427,10 @@ __global__ __launch_bounds__(KS * 64) void merge_scatter_kernel(MergeParams p) {
     }
   }
   const int cnt = 1 + m;
-  const float sum_q = Elem<T>::to_f32(Elem<T>::from_f32(acc));            // the scattered SUM in the model dtype
+  const uint32_t sq = round_pack2<T>(acc.x, acc.y);                       // the scattered SUM in the model dtype
   const float cnt_q = Elem<T>::to_f32(Elem<T>::from_f32((float)cnt));     // the count in the model dtype (rounds above 256 / 2048)
   uint16_t* out = reinterpret_cast<uint16_t*>(is_v ? p.v_out : p.k_out) + ((int64_t)bh * nt + j) * D + d;
-  *out = Elem<T>::from_f32(sum_q / cnt_q);
+  *reinterpret_cast<uint32_t*>(out) = round_pack2<T>(Elem<T>::to_f32((uint16_t)(sq & 0xffffu)) / cnt_q, Elem<T>::to_f32((uint16_t)(sq >> 16)) / cnt_q);
 }
 
 template <typename T, int KS>
@@ -436,7 +442,7 @@ hipError_t launch_merge_t(const MergeParams& p, hipStream_t st) {
   hipLaunchKernelGGL((merge_targets_kernel<T, KS>), gt, dim3(256), 0, st, p);
   hipLaunchKernelGGL((merge_pivot_kernel<T, KS>), gp, dim3(256), 0, st, p);
   hipLaunchKernelGGL(merge_bucket_kernel, dim3(p.B * p.H), dim3(1024), 0, st, p);
-  hipLaunchKernelGGL((merge_scatter_kernel<T, KS>), gs, dim3(KS * 64), bitmap_bytes, st, p);
+  hipLaunchKernelGGL((merge_scatter_kernel<T, KS>), gs, dim3(KS * 32), bitmap_bytes, st, p);
   return hipGetLastError();
 }
 
