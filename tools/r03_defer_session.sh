@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 3: logits stores deferred by one stage (libpkv.so) against the previous build (libpkv_base.so), over stages per workgroup
+# Record of a finished experiment (results: profiles/r03/ab/).  libpkv_base.so = the build of the commit before 'logits2: the logits of a stage leave one stage later',
+# copied next to libpkv.so before the session (PKV_LIB selects a build of the same ABI, pyramidkv_amd/_native.py).
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 3: single-stage logits workgroups with LDS-direct K rows (libpkv.so) against the deferred-store build (libpkv_defer.so)
+# Record of a finished experiment (results: profiles/r03/ab/).  libpkv_defer.so = the build of HEAD at the time (deferred stores, register-staged K rows); libpkv.so was the LDS-direct variant, since removed,
+# copied next to libpkv.so before the session (PKV_LIB selects a build of the same ABI, pyramidkv_amd/_native.py).
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
