@@ -334,8 +334,8 @@ __global__ __launch_bounds__(1024) void merge_bucket_kernel(MergeParams p) {
 // Workgroup = one kept row of one (b,h): threads 0..D/2-1 = the KEY row (two adjacent elements each), D/2..D-1 the VALUE row.  The group
 // arrives unordered; the reference accumulates in ascending position (fp32, scatter_reduce walks the source in order), so
 // the positions are set as bits of an LDS bitmap over [0, S) and read back in order: a popcount prefix gives every set bit
-// its rank, MS_CAP ranks at a time become the list of a walk.  The walk keeps two batches of row loads in flight (the next
-// batch is issued before the current one is consumed): the accumulation order is the list order, whatever the latency.
+// its rank, MS_CAP ranks at a time become the list of a walk.  The walk issues the MS_B row loads of a batch together and
+// consumes them in list order: the accumulation order is the list order, whatever the latency of a row.
 constexpr int MS_CAP = 2048;              // list entries per pass
 constexpr int MS_B = 32;                  // rows per batch of the walk (all in flight together)
 
