@@ -80,6 +80,25 @@ def test_strerror_and_argument_validation_without_gpu(P):
     d.S = 8192
     assert N.lib.pkv_compress(d, 16, 16, 16, 16, 16, None, 16, 1 << 30, None) == -5          # fp32 top-k: k <= 4096
     assert N.lib.pkv_topk(2, 1, 9000, 4097, 16, 9000, None, 16, 4097, None) == -5
+    # pkv_merge_compact (round 3): head sizes 64 / 128 / 256, bf16 / fp16; S within the scatter kernel's LDS bitmap, kept rows
+    # within the 16-bit row numbers of the pivot keys; the workspace grows with the head size
+    m = N.PkvDesc()
+    m.dtype, m.B, m.H, m.S, m.D, m.kv_group, m.window, m.topk = 0, 1, 2, 4096, 64, 1, 8, 120
+    for i in range(3):
+        m.k_stride[i] = m.v_stride[i] = m.q_stride[i] = 64
+    mc = lambda ws_bytes=1024: N.lib.pkv_merge_compact(m, 16, 16, 16, m.topk, 16, 16, 16, ws_bytes, None)   # noqa: E731
+    need64 = N.lib.pkv_merge_workspace_bytes(m)
+    assert need64 > 0 and mc() == -4                                    # accepted at D = 64: only the workspace is short
+    m.D = 256
+    assert N.lib.pkv_merge_workspace_bytes(m) > need64 and mc() == -4
+    m.dtype = 2
+    assert mc() == -5                                                   # fp32 merge
+    m.dtype, m.D, m.S = 1, 128, 393217
+    assert mc() == -5                                                   # longer than the position bitmap
+    m.S, m.topk = 200000, 65530
+    assert mc() == -5                                                   # 65 538 kept rows
+    m.topk = 65527
+    assert mc() == -4                                                   # 65 535 kept rows: accepted
     with pytest.raises(ValueError):
         N.check(-2, "x")
     with pytest.raises(N.PkvError):
