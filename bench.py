@@ -10,9 +10,12 @@ Workload (BASELINE.json metric: "prefill tokens/s + KV-compress ms at S=32k budg
   Llama-3-8B attention shapes H=32, D=128, S=32768, bf16, synthetic N(0,1) Q/K/V resident in HBM.
   One STEP = the compress work of one model prefill: 32 update_kv calls, layer budgets 234..17
   (pyramidkv_utils.py:205-215), each on a [B,H,S,D] batch.  value = B*S*steps / time.
-Multi-GPU: head-sharded, one RCCL all-gather of the selected indices per layer (pyramidkv_amd/dist.py).  Two legs are
-timed and reported in `scaling_legs`: "weak" (rank r owns H/N heads of B = N sequences: per-GPU bytes fixed; this is
-`value`) and "strong_config4" (BASELINE config 4: ONE 32k sequence, H/N heads per GPU).
+The step calls the operator API the reference exposes - 32 pre-built PyramidKVCluster objects, `update_kv(K, Q, V, None, g)`
+(pyramidkv_utils.py:197) - not the layer below it.
+Multi-GPU (N > 1): the headline IS BASELINE config 4 - ONE [1,32,32768,128] sequence, head-sharded: rank r owns 32/N query
+heads and their 8/N un-expanded KV heads (one KV head per GPU at N = 8), one RCCL all-gather of the selected indices
+(pyramidkv_amd/dist.py); "scaling": "strong".  The embarrassingly parallel weak leg (B = N sequences, H/N heads of each
+per GPU) is reported under `scaling_legs`, next to the all-gather's own latency.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   `roofline`          dominant kernel (the K scan) of the headline workload,
@@ -54,6 +57,7 @@ def parse():
     ap.add_argument("--seq", type=int, default=32768)
     ap.add_argument("--budget", type=int, default=128)
     ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=8, help="KV heads of the model (Llama-3-8B: 8); the N > 1 headline shards them un-expanded")
     ap.add_argument("--batch", type=int, default=0, help="0 = one sequence per GPU (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--policy", default="pyramidkv", choices=["pyramidkv", "snapkv"])
@@ -99,12 +103,22 @@ def kernel_src_sha16():
     return h.hexdigest()[:16]
 
 
-def make_sets(B, Hl, S, dt, dev, seed, nsets):
+def make_sets(B, Hl, S, dt, dev, seed, nsets, Hkv=None):
+    """(Q, K, V) sets; Hkv < Hl: K/V un-expanded ([B,Hkv,S,D] next to Q [B,Hl,S,D])."""
     gen = torch.Generator(device=dev).manual_seed(seed)
     sets = []
     for _ in range(nsets):
-        sets.append(tuple(torch.randn(B, Hl, S, D, generator=gen, device=dev, dtype=torch.float32).to(dt) for _ in range(3)))
+        sets.append(tuple(torch.randn(B, Hl if i == 0 or Hkv is None else Hkv, S, D, generator=gen, device=dev, dtype=torch.float32).to(dt)
+                          for i in range(3)))
     return sets
+
+
+def make_clusters(P, policy, cap):
+    """The operator objects the reference builds per layer (init_pyramidkv / init_snapkv, pyramidkv_utils.py:880-935)."""
+    if policy == "pyramidkv":
+        return [P.PyramidKVCluster(num_hidden_layers=NUM_LAYERS, layer_idx=layer, window_size=W, max_capacity_prompt=cap,
+                                   kernel_size=7, pooling="maxpool") for layer in range(NUM_LAYERS)]
+    return [P.SnapKVCluster(window_size=W, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool") for _ in range(NUM_LAYERS)]
 
 
 def self_launch(a):
@@ -176,8 +190,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    clusters = make_clusters(P, a.policy, cap)
+
     def timed_leg(B, steps, warmup, sets):
         xch = pdist.PrefillIndexExchange(ks, B, Hl, dev, force=collective) if (collective and a.allgather == "prefill") else None
+        # every layer's update_kv also leaves its selected indices in a buffer: the exchange's slot, or a plain tensor
+        slots = [xch.slot(layer) if xch is not None else torch.empty(B, Hl, ks[layer], dtype=torch.int32, device=dev)
+                 for layer in range(NUM_LAYERS)]
+        g = sets[0][0].shape[1] // sets[0][1].shape[1]         # query heads per KV head handed over (1 = expanded K/V)
 
         def one_step(keep=None):
             # The one exchange step of the path: the selected indices (KBs).  No layer's update_kv depends on another layer's
@@ -187,10 +207,10 @@ def main():
             outs, pending = None, []
             for layer in range(NUM_LAYERS):
                 q, k, v = sets[layer % len(sets)]
-                if xch is not None:
-                    kc, vc, idx = P.ops.compress(q, k, v, W, ks[layer], "maxpool", 7, idx_out=xch.slot(layer))
-                else:
-                    kc, vc, idx = P.ops.compress(q, k, v, W, ks[layer], "maxpool", 7, return_indices=True)
+                cl = clusters[layer]
+                cl.index_out = slots[layer]
+                kc, vc = cl.update_kv(k, q, v, None, g)
+                idx = slots[layer]
                 if keep is not None and layer in keep:
                     keep[layer] = (kc, vc, idx.clone())
                 if xch is None:
@@ -217,12 +237,27 @@ def main():
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, one_step
+        ag_us = None
+        if xch is not None:                  # the collective alone: issue + wait, nothing else on the device
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                xch.views(xch.gather_async())
+            torch.cuda.synchronize()
+            ag_us = (time.perf_counter() - t0) / 20 * 1e6
+        return el, one_step, ag_us
 
-    # ---- headline leg: weak scaling (B = N unless --batch) ----
-    B = a.batch if a.batch > 0 else world
-    sets = make_sets(B, Hl, S, dt, dev, 1234 + rank, NSETS)
-    el, one_step = timed_leg(B, a.steps, a.warmup, sets)
+    # ---- headline leg ----
+    # N = 1: one [B,H,S,D] sequence batch with K/V as the reference's update_kv receives them (after repeat_kv).
+    # N > 1: BASELINE config 4 - ONE sequence, rank r owns H/N query heads and their KV heads UN-EXPANDED (Llama-3-8B: 8 KV
+    # heads, one per GPU at N = 8); strong scaling.  --batch B overrides the batch size.
+    strong = world > 1 and a.batch == 0
+    B = a.batch if a.batch > 0 else 1
+    Hkv = None
+    if strong and a.kv_heads % world == 0 and (H // a.kv_heads) * W <= 256:
+        Hkv = a.kv_heads // world
+    sets = make_sets(B, Hl, S, dt, dev, 1234 + rank, NSETS, Hkv)
+    el, one_step, ag_us = timed_leg(B, a.steps, a.warmup, sets)
     ms_per_step = el / a.steps * 1e3
     tokens_per_s = B * S * a.steps / el
     # ---- parity of the TIMED path: the step function that was just timed, layers 0 and 31, against the CPU oracle ----
@@ -253,10 +288,10 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_ms * 1e3, 2),
                 "launches": int(n), "algorithmic_bytes": int(bytes_per_launch)}
 
-    def alg_bytes(B_, Hl_, S_, k_mean):
+    def alg_bytes(B_, Hl_, S_, k_mean, g_=1):
         n = B_ * Hl_
         return {
-            "logits": n * (S_ * D * E + W * D * E),                      # K read once + the w query rows
+            "logits": (n // g_) * S_ * D * E + n * W * D * E,            # K read once per KV head + the w query rows
             "finalize": n * (W * S_ * E + (S_ - W) * E),                 # logits [w][S] read once, pooled scores written
             "topk": n * ((S_ - W) * E + k_mean * 4),
             "gather": 4 * (k_mean + W) * D * E * n,                      # 2 tensors x (k+w) rows x D x e x (read+write)
@@ -271,7 +306,7 @@ def main():
                 rows_[name] = r
         return rows_
 
-    alg = alg_bytes(B, Hl, S, sum(ks) / NUM_LAYERS)
+    alg = alg_bytes(B, Hl, S, sum(ks) / NUM_LAYERS, (Hl // Hkv) if Hkv else 1)
     kernels = kernel_rows(prof, alg)
     # HBM traffic per launch from rocprofv3 PMC passes (tools/pmc_summary.py).  Only attached when the profile was taken
     # from exactly these kernel sources and this workload; otherwise the field stays null instead of going stale.
@@ -304,11 +339,15 @@ def main():
         "metric": "prefill tokens/s through KV-compress (PyramidKV budget=%d, S=%d, Llama-3-8B shapes)" % (cap, S),
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "kv_compress_ms_per_layer": round(ms_per_step / NUM_LAYERS, 5),
-        "higher_is_better": True, "scaling": "weak" if a.batch == 0 else "strong", "vs_baseline": None, "dtype": a.dtype,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype,
         "data": "synthetic",
-        "config": {"workload": "%s budget=%d window=8 maxpool7, 32 layer-calls/step, [B=%d,H=%d,S=%d,D=128] %s"
+        "config": {"workload": "%s budget=%d window=8 maxpool7, 32 update_kv calls/step, [B=%d,H=%d,S=%d,D=128] %s"
                                % (a.policy, cap, B, H, S, a.dtype),
                    "global_batch": B, "seq_len": S, "heads_per_gpu": Hl,
+                   "kv_heads_per_gpu": Hkv if Hkv else Hl,
+                   "kv_layout": ("un-expanded GQA: %d of the model's %d KV heads per GPU, kv_group %d" % (Hkv, a.kv_heads, Hl // Hkv)) if Hkv
+                                else "expanded (after repeat_kv, as the reference's update_kv receives it)",
+                   "timed_through": "PyramidKVCluster.update_kv" if a.policy == "pyramidkv" else "SnapKVCluster.update_kv",
                    "parallelism": ("head-shard x%d + 1 all-gather(indices) per %s" % (world, a.allgather)) if collective else "single GPU",
                    "collective_backend": (backend if collective else None)},
         "roofline": kernels.get("logits"),
@@ -319,24 +358,26 @@ def main():
     if collective:
         out["config"]["process_group_backend"] = dist.get_backend()
         out["rccl_nranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else None
+        out["allgather_us"] = round(ag_us, 1) if ag_us is not None else None      # one all-gather of the whole prefill's indices, alone
     # whole-call effective bandwidth: all algorithmic bytes of a call / its wall time
     out["call_effective"] = {"GBps": round(sum(alg.values()) / (ms_per_step / NUM_LAYERS * 1e-3) / 1e9, 1),
                              "frac_of_8TBps": round(sum(alg.values()) / (ms_per_step / NUM_LAYERS * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del sets
     torch.cuda.empty_cache()
 
-    # ---- second multi-GPU leg: BASELINE config 4 = ONE 32k sequence, H/N heads per GPU (strong scaling) ----
-    if world > 1 and a.batch == 0 and not a.no_extras:
-        ssets = make_sets(1, Hl, S, dt, dev, 99 + rank, NSETS)
-        sel, _ = timed_leg(1, a.steps, 1, ssets)
+    # ---- second multi-GPU leg: weak scaling (B = N sequences, H/N expanded heads of each per GPU: per-GPU bytes constant) ----
+    if strong and not a.no_extras:
+        wsets = make_sets(world, Hl, S, dt, dev, 99 + rank, 2)
+        wel, _, _ = timed_leg(world, a.steps, 1, wsets)
         out["scaling_legs"] = {
-            "weak": {"global_batch": B, "tokens_per_s": round(tokens_per_s, 1), "ms_per_step": round(ms_per_step, 4),
-                     "note": "B = N sequences, H/N heads of each per GPU: per-GPU bytes constant (this is `value`)"},
-            "strong_config4": {"global_batch": 1, "tokens_per_s": round(S * a.steps / sel, 1),
-                               "ms_per_step": round(sel / a.steps * 1e3, 4),
-                               "kv_compress_ms_per_layer": round(sel / a.steps / NUM_LAYERS * 1e3, 5),
-                               "note": "BASELINE config 4: one 32k sequence, %d heads per GPU; latency-bound tail" % Hl}}
-        del ssets
+            "strong_config4": {"global_batch": 1, "tokens_per_s": round(tokens_per_s, 1), "ms_per_step": round(ms_per_step, 4),
+                               "kv_compress_ms_per_layer": round(ms_per_step / NUM_LAYERS, 5),
+                               "note": "BASELINE config 4 (this is `value`): one 32k sequence, %d query heads%s per GPU; every call is a "
+                                       "%.1f MB K scan under a ~20 us latency tail, so this leg cannot scale linearly (DESIGN.md section 7)"
+                                       % (Hl, (" / %d KV heads" % Hkv) if Hkv else "", (Hkv or Hl) * S * D * E / 1e6)},
+            "weak": {"global_batch": world, "tokens_per_s": round(world * S * a.steps / wel, 1), "ms_per_step": round(wel / a.steps * 1e3, 4),
+                     "note": "B = N sequences, H/N expanded heads of each per GPU: per-GPU bytes constant, no data-path dependency between ranks"}}
+        del wsets
         torch.cuda.empty_cache()
 
     if world == 1 and a.only_gqa_extra:
@@ -374,6 +415,8 @@ def parity_block(keep, sets, ks, cap, a, S):
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     for layer, got in sorted(keep.items()):
         q, k, v = (t[:1].cpu() for t in sets[layer % len(sets)])
+        if k.shape[1] != q.shape[1]:                                   # un-expanded K/V: the oracle takes what repeat_kv hands the reference
+            k, v = (t.repeat_interleave(q.shape[1] // t.shape[1], dim=1) for t in (k, v))
         kc, vc, idx = (t[:1].cpu() for t in got)
         with contextlib.redirect_stdout(io.StringIO()):
             if a.policy == "pyramidkv":
@@ -402,30 +445,33 @@ def parity_block(keep, sets, ks, cap, a, S):
 
 
 def seq_batch_sweep(P, dt, dev, H, alg_bytes):
-    """The synthetic sweep BASELINE.json names ([B = 1..8, H = 32, S = 4k..32k, D = 128]): one SnapKV budget-128 update_kv
-    per point, wall time per call (events around 10 calls on rotating inputs) as tokens/s and as a fraction of the HBM
-    roofline over the call's algorithmic bytes."""
+    """The synthetic sweep BASELINE.json names ([B = 1..8, H = 32, S = 4k..32k, D = 128]): one SnapKVCluster.update_kv (budget
+    128) per point, wall time per call (events around 10 calls on rotating inputs) as tokens/s and as a fraction of the HBM
+    roofline over the call's algorithmic bytes; `host_us` = host time to issue one call."""
     rows = []
     for S in (4096, 8192, 16384, 32768):
         for B in (1, 2, 4, 8):
             k_sel = 128 - W
             nset = max(2, min(4, int(1.6e9 // (3 * B * H * S * 256))))
             sets = make_sets(B, H, S, dt, dev, 100 + B + S, nset)
+            cl = P.SnapKVCluster(window_size=W, max_capacity_prompt=128, kernel_size=7, pooling="maxpool")
             for it in range(3):
                 q, k, v = sets[it % len(sets)]
-                P.ops.compress(q, k, v, W, k_sel, "maxpool", 7)
+                cl.update_kv(k, q, v, None, 1)
             torch.cuda.synchronize()
             iters = 10
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+            h0 = time.perf_counter()
             for it in range(iters):
                 q, k, v = sets[it % len(sets)]
-                P.ops.compress(q, k, v, W, k_sel, "maxpool", 7)
+                cl.update_kv(k, q, v, None, 1)
+            host_us = (time.perf_counter() - h0) / iters * 1e6       # host time to ISSUE one call (no sync): the floor a faster GPU path runs into
             ev1.record()
             torch.cuda.synchronize()
             call_us = ev0.elapsed_time(ev1) / iters * 1e3
             alg = alg_bytes(B, H, S, k_sel)
-            rows.append({"B": B, "S": S, "update_kv_us": round(call_us, 2), "tokens_per_s": round(B * S / call_us * 1e6, 0),
+            rows.append({"B": B, "S": S, "update_kv_us": round(call_us, 2), "host_us": round(host_us, 2), "tokens_per_s": round(B * S / call_us * 1e6, 0),
                          "call_effective_frac_of_8TBps": round(sum(alg.values()) / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
             del sets
             torch.cuda.empty_cache()

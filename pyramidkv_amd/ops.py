@@ -15,10 +15,9 @@ from . import _native as N
 _WS: Dict[Tuple[int, int], torch.Tensor] = {}
 # Superseded workspaces stay alive while a HIP graph captured earlier may still have their address baked in.  Growth is
 # geometric (every new buffer is >= 2x the one it supersedes), so per (device, stream) the retired buffers sum to less than
-# the live one; the list itself is bounded: beyond _WS_RETIRED_MAX entries the oldest are released (release_workspaces()
+# the live one and number ~log2(largest / 1 MB); they are never released behind the caller's back (release_workspaces()
 # drops everything, e.g. between serving sessions once no captured graph is replayed any more).
-_WS_RETIRED: list = []
-_WS_RETIRED_MAX = 64
+_WS_RETIRED: Dict[Tuple[int, int], list] = {}
 
 
 def _require_gpu(*ts):
@@ -45,8 +44,7 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
-            _WS_RETIRED.append(ws)
-            del _WS_RETIRED[:-_WS_RETIRED_MAX]
+            _WS_RETIRED.setdefault(key, []).append(ws)     # never trimmed: a captured graph may still replay with this address
         ws = torch.empty(max(nbytes, 2 * ws.numel() if ws is not None else 0, 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = ws
     return ws

@@ -88,6 +88,9 @@ class _WindowPolicy:
     pooling: str
 
     accepts_unexpanded_kv = True      # update_kv also takes K/V with H/g heads (before repeat_kv)
+    # optional contiguous int32 [B, H, k] tensor: update_kv ALSO writes the selected indices there (a head-sharded host
+    # all-gathers them, pyramidkv_amd/dist.py; bench.py reads them back for its parity block).  Not a reference attribute.
+    index_out = None
 
     def _compress(self, key_states, query_states, value_states, k, num_key_value_groups, h2o=False):
         gu = _unexpanded_group(key_states, query_states)
@@ -110,13 +113,13 @@ class _WindowPolicy:
             return ops.merge_compact(ks, vs, idx, self.window_size, kv_group=g)
         if gu > 1:
             return ops.compress(query_states, key_states, value_states, self.window_size, k, self.pooling,
-                                self.kernel_size, scale_mode=_cfg.scale_mode, kv_group=gu, h2o=h2o)
+                                self.kernel_size, scale_mode=_cfg.scale_mode, kv_group=gu, h2o=h2o, idx_out=self.index_out)[:2]
         g = _kv_group(num_key_value_groups, query_states.shape[1])
         if g * self.window_size > _MAX_COLS:
             g = 1
         return ops.compress(query_states, _dedup_view(key_states, g), _dedup_view(value_states, g),
                             self.window_size, k, self.pooling, self.kernel_size,
-                            scale_mode=_cfg.scale_mode, kv_group=g, h2o=h2o)
+                            scale_mode=_cfg.scale_mode, kv_group=g, h2o=h2o, idx_out=self.index_out)[:2]
 
     @staticmethod
     def _passthrough(key_states, query_states, value_states):

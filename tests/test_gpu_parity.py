@@ -304,6 +304,45 @@ def test_h2o_scores(P, dt):
         assert mx <= 1 and frac <= H2O_MISMATCH_FRAC, (frac, mx)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_h2o_scores_key_norm_outliers(P, dt):
+    """Pass 1 of the H2O kernels takes its exponentials relative to the bound |q| max|k| / sqrt(D) - 64 and repeats a
+    workgroup's rows with the exact running maximum when a row's logits sit more than ~105 below that bound
+    (pkv_h2o.hip).  Keys with a huge norm in a direction no query looks at put EVERY row there; an outlier that only
+    the queries of one workgroup look at mixes both paths in one launch; very large logits keep the bound path."""
+    S, w, D = 1200, 8, 128
+    for case in ("all_rows_repeat", "some_rows_repeat", "large_logits"):
+        # large logits on the lattice: every q.k is an exact multiple of 16 below 2^15 (no accumulation-order rounding of the
+        # model-dtype logits, whose unit is up to 4 there - one flipped logit moves a probability by several per cent)
+        q, k, _ = make_qkv(1, 2, S, D, dt, "lattice" if case == "large_logits" else "gauss", 97)
+        if case == "all_rows_repeat":
+            q[..., 0] = 0
+            k[:, :, 5::300, :] = 0
+            k[:, :, 5::300, 0] = 3000.0 if dt == "bf16" else 2000.0           # bound ~ 11 * 3000 / 11.3 = 2900
+        elif case == "some_rows_repeat":
+            q[:, :, :256, :] *= 0.01                                          # first workgroup: queries along the outlier key,
+            q[:, :, :256, 0] = 3.0                                            # row maximum = bound / 1.02: inside the window
+            q[:, :, 256:, 0] = 0                                              # all other rows: ~400 below their bound
+            k[:, :, 7, :] = 0
+            k[:, :, 7, 0] = 1500.0
+        else:
+            q *= 16
+            k *= 16                                                           # logits ~ N(0, 106^2): row maxima ~ 350, bound ~ 1500
+        want = O.h2o_scores(q, k, w)
+        got = P.ops.score_h2o(q.to(DEV), k.to(DEV), w).cpu()
+        assert torch.isfinite(got.float()).all(), case
+        # probabilities below 2^-126 are +0 on the GPU (hardware exp2, MFMA operands): scores down there come out as 0
+        tiny = want.float().abs() < 1e-35
+        assert (got.float()[tiny].abs() < 1e-35).all()
+        got, want = got.clone(), want.clone()
+        got[tiny] = 0
+        want[tiny] = 0
+        frac, mx = score_diff(got, want)
+        _report(f"h2o_scores_outliers/{dt}/{case}", dict(mismatch_frac=frac, max_ulp=mx))
+        # 2384 scores per case: a handful of one-unit differences (round 3's kernels: 5 on the fp16 lattice case) is the bar
+        assert mx <= 1 and frac <= max(H2O_MISMATCH_FRAC, 8.0 / got.numel()), (case, frac, mx)
+
+
 # ----------------------------------------------------------------------------------------- end to end
 def _self_consistent(P, cl_out, q, k, v, w, kk, scores_gpu):
     """indices == canonical top-k of the kernel's own scores; K/V == exact gather of them."""
