@@ -196,6 +196,9 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     // (one stage per workgroup costs +4 us there).  Round 3, after the logits stores moved one stage back (pkv_score.hip):
     // same ranking - C = 8: 44.3 us at 1 stage, 46.2 / 45.6 / 46.4 / 47.3 at 2 / 4 / 8 / 16; C = 32: 16.8 us at 2 stages
     // (1024 workgroups), 17.2 at 3, 17.3 at 4, 20.1 at 1 (profiles/r03/ab/defer_stores_ab.txt, one_stage_lds_direct_ab.txt).
+    // Round 4 measured the review's "every finalize workgroup re-merges all partials of its head" (256 per row at one stage per
+    // workgroup): 8 stages per workgroup at B = 8 (32 partials per row) left finalize_kernel at 44.5 us - it is bound by its
+    // ~790 vector instructions per wave, not by those reads - and the K scan at 344 us.  One stage stays.
     const int64_t target = logits_v2_wgs() > 0 ? logits_v2_wgs() : (C > 8 ? (int64_t)4 * cus : total);
     int nst = (int)((total + target - 1) / target);
     nst = std::max(1, std::min(nst, std::min(sph, 64)));

@@ -60,6 +60,35 @@ def point(B, S, dt, seed):
     return rows
 
 
+def h2o_point(B, Hh, S, dt, seed):
+    """H2O rows (round 4): score-mismatch fraction of the kernels' scores against the oracle's (row-blocked above 4096 keys),
+    and the selection of both budgets.  The oracle costs S^2 per head on the host, so H and S are smaller than above."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    q, k, v = (torch.randn(B, Hh, S, D, generator=g, device=DEV, dtype=torch.float32).to(dt) for _ in range(3))
+    qc, kc_, vc_ = q.cpu(), k.cpu(), v.cpu()
+    want = O.h2o_scores(qc, kc_, W) if S <= 4096 else O.h2o_scores_blocked(qc, kc_, W, block=512)
+    got = P.ops.score_h2o(q, k, W).cpu()
+    d = (mono16(got) - mono16(want)).abs()
+    order = O.topk_canonical(want, min(2048 - W, S - W))
+    rows = []
+    for cap in (128, 2048):
+        kk = cap - W
+        kc, vc, idx = P.ops.compress(q, k, v, W, kk, None, 1, h2o=True, return_indices=True)
+        ridx = order[..., :kk]
+        ia = idx.cpu().long()
+        seq = (ia == ridx).all(-1)
+        st = (torch.sort(ia, -1).values == torch.sort(ridx, -1).values).all(-1)
+        kr, vr = O.gather_compact(kc_, vc_, ridx, W)
+        kv = (kc.cpu() == kr).flatten(2).all(-1) & (vc.cpu() == vr).flatten(2).all(-1)
+        key = mono16(torch.gather(want, -1, ia))
+        max_inv = int((key[..., 1:] - key[..., :-1]).max().item())
+        rows.append({"policy": "h2o", "B": B, "H": Hh, "S": S, "dtype": str(dt).replace("torch.", ""), "budget": cap, "heads": seq.numel(),
+                     "score_mismatch_frac": round(float((d > 0).float().mean()), 7), "score_max_ulp": int(d.max()),
+                     "heads_identical_set": int(st.sum()), "heads_identical_sequence": int(seq.sum()),
+                     "kv_bit_identical_heads": int(kv.sum()), "max_order_inversion_ulp": max(max_inv, 0)})
+    return rows
+
+
 def main():
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     out = {"workload": "SnapKV window 8 maxpool-7, H=32, D=128, N(0,1) inputs; HIP path vs oracle (canonical tie order)", "rows": []}
@@ -73,6 +102,26 @@ def main():
                     break
                 out["rows"] += point(B, S, dt, 9000 + B * 131 + S)
                 torch.cuda.empty_cache()
+    # H2O (no pooling, all S query rows): B in {1, 2} x S in {4k, 8k} x both dtypes, 8 heads
+    out["h2o_rows"] = []
+    t1 = time.time()
+    for dt in (torch.bfloat16, torch.float16):
+        for S in (4096, 8192):
+            for B in (1, 2):
+                if time.time() - t1 > float(os.environ.get("PKV_PARITY_SWEEP_H2O_SECONDS", "240")):
+                    out["h2o_truncated_at"] = {"dtype": str(dt), "S": S, "B": B}
+                    break
+                out["h2o_rows"] += h2o_point(B, 8, S, dt, 7000 + B * 17 + S)
+                torch.cuda.empty_cache()
+    hr = out["h2o_rows"]
+    if hr:
+        th = sum(r["heads"] for r in hr)
+        out["h2o_summary"] = {"points": len(hr), "heads": th,
+                              "score_mismatch_frac_max": max(r["score_mismatch_frac"] for r in hr), "score_max_ulp": max(r["score_max_ulp"] for r in hr),
+                              "set_rate": sum(r["heads_identical_set"] for r in hr) / th, "sequence_rate": sum(r["heads_identical_sequence"] for r in hr) / th,
+                              "by_budget": {str(c): {"heads": sum(r["heads"] for r in hr if r["budget"] == c),
+                                                     "sequence_rate": sum(r["heads_identical_sequence"] for r in hr if r["budget"] == c)
+                                                     / max(1, sum(r["heads"] for r in hr if r["budget"] == c))} for c in (128, 2048)}}
     rows = out["rows"]
     tot = sum(r["heads"] for r in rows)
     out["summary"] = {
@@ -90,6 +139,7 @@ def main():
     with open(os.path.join(ROOT, "gpurun_out", "parity_sweep.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out["summary"]))
+    print(json.dumps(out.get("h2o_summary")))
 
 
 if __name__ == "__main__":
