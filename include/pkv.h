@@ -27,6 +27,8 @@ extern "C" {
 #endif
 
 #define PKV_VERSION 100 /* 0.1.0 */
+/* libpkv.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table (plus nothing). */
+#define PKV_API __attribute__((visibility("default")))
 
 typedef void* pkv_stream_t; /* hipStream_t */
 
@@ -68,64 +70,64 @@ typedef struct pkv_desc {
   int32_t topk;         /* k = past tokens kept per head, 1..S-window (host-resolved per layer) */
 } pkv_desc;
 
-int pkv_version(void);
-const char* pkv_strerror(int status);
-int pkv_last_hip_error(void); /* hipError_t of the last PKV_ERR_HIP on this thread */
+PKV_API int pkv_version(void);
+PKV_API const char* pkv_strerror(int status);
+PKV_API int pkv_last_hip_error(void); /* hipError_t of the last PKV_ERR_HIP on this thread */
 
 /* Bytes of scratch pkv_score_window / pkv_score_h2o / pkv_compress need for `d` (256-B aligned). */
-size_t pkv_workspace_bytes(const pkv_desc* d);
+PKV_API size_t pkv_workspace_bytes(const pkv_desc* d);
 
 /* Observation-window score (pyramidkv_utils.py:317-333, AdaKV :649-672):
  *   logits = (Q[-w:] K^T)/sqrt(D) -> causal corner mask -> fp32 softmax over all S keys -> round
  *   -> sum/mean of the w rows over columns [0,S-w) -> round -> avg/max pool.
  * scores_out: [B*H rows][scores_stride] elements of d->dtype, columns [0, S-w) written. */
-int pkv_score_window(const pkv_desc* d, const void* q, const void* k, void* scores_out,
+PKV_API int pkv_score_window(const pkv_desc* d, const void* q, const void* k, void* scores_out,
                      int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream);
 
 /* H2O score (pyramidkv_utils.py:544-554,561): all S query rows, SxS never materialised.
  * Same output layout as pkv_score_window; no pooling. */
-int pkv_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores_out,
+PKV_API int pkv_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores_out,
                   int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream);
 
 /* Top-k token selection (pyramidkv_utils.py:334, :238, :270, :562): for each of `rows` score rows
  * of length L pick the k largest, emitted in (value desc, index asc) order as int32.
  * scores: [rows][scores_stride] of dtype; idx_out: [rows][idx_stride] int32.
  * k_per_row (device int32[rows], may be NULL) overrides k per row (k = upper bound then). */
-int pkv_topk(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores,
+PKV_API int pkv_topk(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores,
              int64_t scores_stride, const int32_t* k_per_row, int32_t* idx_out, int64_t idx_stride,
              pkv_stream_t stream);
 
 /* Rows longer than one workgroup's LDS (L > 57 344 keys; k <= 32 768): the same selection through per-segment
  * top-k + a top-k over the segment winners; needs pkv_topk_workspace_bytes() of 16-B aligned scratch (0 for rows
  * pkv_topk handles itself; k_per_row is not supported on long rows). */
-size_t pkv_topk_workspace_bytes(int32_t rows, int32_t L, int32_t k);
-int pkv_topk_ws(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores,
+PKV_API size_t pkv_topk_workspace_bytes(int32_t rows, int32_t L, int32_t k);
+PKV_API int pkv_topk_ws(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* scores,
                 int64_t scores_stride, const int32_t* k_per_row, int32_t* idx_out, int64_t idx_stride,
                 void* ws, size_t ws_bytes, pkv_stream_t stream);
 
 /* Gather-compaction (pyramidkv_utils.py:335,341-346): K_out/V_out[b,h] = rows idx[b,h,0..k) of
  * K/V[b,h,:S-w] followed by the w window rows S-w..S-1.  Outputs are contiguous [B,H,k+w,D].
  * idx: int32 [B*H][idx_stride].  d->topk = k.  Uses d->k_stride/v_stride/kv_group. */
-int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx,
+PKV_API int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx,
                        int64_t idx_stride, void* k_out, void* v_out, pkv_stream_t stream);
 
 /* StreamingLLM (pyramidkv_utils.py:607-620): idx = 0..k-1 for every head; no scoring. */
-int pkv_gather_streaming(const pkv_desc* d, const void* k, const void* v, void* k_out, void* v_out,
+PKV_API int pkv_gather_streaming(const pkv_desc* d, const void* k, const void* v, void* k_out, void* v_out,
                          pkv_stream_t stream);
 
 /* Fused update_kv for SnapKV / PyramidKV (pyramidkv_utils.py:306-347, :197-283; k resolved by the
  * host per layer): score -> top-k -> gather on `stream`.  idx_out (int32 [B*H][d->topk]) may be NULL
  * (then it lives in ws). */
-int pkv_compress(const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
+PKV_API int pkv_compress(const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
                  void* v_out, int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream);
 
 /* Fused update_kv for H2O (pyramidkv_utils.py:533-575). */
-int pkv_compress_h2o(const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
+PKV_API int pkv_compress_h2o(const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
                      void* v_out, int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream);
 
 /* Selection only: the front half of pkv_compress / pkv_compress_h2o (score -> top-k), idx_out int32 [B*H][d->topk].
  * What a caller needs when something other than the plain gather follows (the merge below).  ws: pkv_workspace_bytes(d). */
-int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int32_t* idx_out, void* ws, size_t ws_bytes,
+PKV_API int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int32_t* idx_out, void* ws, size_t ws_bytes,
                pkv_stream_t stream);
 
 /* LOOK-M pivot merge (pyramidkv_utils.py:119-170 merge_kv(..., merge="pivot"), called from :242,:274,:338,:566,:611 when the
@@ -136,22 +138,22 @@ int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int
  * idx: int32 [B*H][idx_stride] (d->topk = k entries per row, from pkv_select / pkv_topk).  Outputs [B,H,k+w,D] contiguous.
  * ws: pkv_merge_workspace_bytes(d), 16-B aligned.  Rounding points: oracle/pkv_oracle.py merge_kv_explicit.
  * bf16 / fp16, D = 64 / 128 / 256; S <= 393 216 and k + window <= 65 535 (PKV_ERR_UNSUPPORTED beyond, and for fp32). */
-size_t pkv_merge_workspace_bytes(const pkv_desc* d);
-int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx, int64_t idx_stride,
+PKV_API size_t pkv_merge_workspace_bytes(const pkv_desc* d);
+PKV_API int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx, int64_t idx_stride,
                       void* k_out, void* v_out, void* ws, size_t ws_bytes, pkv_stream_t stream);
 
 /* ---- Ada-SnapKV / HeadKV (pyramidkv_utils.py:674-757, :808-878): flat var-len output ---- */
 
 /* Per-row full descending sort (:706 attn_score.sort(descending=True)), ties index-ascending.
  * sorted_idx: int32 [rows][L]; sorted_val (may be NULL): dtype [rows][L].  L <= 32768. */
-int pkv_sort_rows(int32_t dtype, int32_t rows, int32_t L, const void* scores, int64_t scores_stride,
+PKV_API int pkv_sort_rows(int32_t dtype, int32_t rows, int32_t L, const void* scores, int64_t scores_stride,
                   int32_t* sorted_idx, void* sorted_val, pkv_stream_t stream);
 
 /* Head budgets (:709-719): optional normalisation, global top-(H*base) over the flattened sorted
  * scores, per-head counts, cap_h = round(count*(1-floor) + int(base*floor)).
  * sorted_val: dtype [H][L] (from pkv_sort_rows).  Writes int32 head_capacity[H] (device).
  * ws: >= 1024 + 2*H*256*4 bytes.  H <= 256.  B must be 1 (:724). */
-int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, int32_t base_capacity,
+PKV_API int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, int32_t base_capacity,
                    double floor_ratio, int32_t normalize, int32_t* head_capacity, void* ws,
                    size_t ws_bytes, pkv_stream_t stream);
 
@@ -161,7 +163,7 @@ int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, 
  * L (the sum over all scores of :710 is taken from them).  M >= min(L, H*base) is checked.  Same ws as pkv_ada_budget.
  * head_lens / cu_klen (both or neither; device int32 [H] / [H+1]): when given, the var-len metadata of pkv_ada_metadata
  * for `window` is written by the same launch. */
-int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const void* scores, int64_t scores_stride,
+PKV_API int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const void* scores, int64_t scores_stride,
                         const int32_t* top_idx, int64_t idx_stride, int32_t base_capacity, double floor_ratio,
                         int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens, int32_t* cu_klen,
                         void* ws, size_t ws_bytes, pkv_stream_t stream);
@@ -175,7 +177,7 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
  * int32 [H]): inclusive prefix of head_lens (:687).  host_mirror (optional): device-visible PINNED HOST int32 [H+1]: gets the
  * capacities, then host_seq in word H (release, system scope) - the host polls it instead of copy + stream synchronise.
  * The gather then needs, per head, its first cap_h entries of the canonical order: pkv_topk with k_per_row = head_capacity. */
-int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores, int64_t scores_stride, int32_t base_capacity,
+PKV_API int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores, int64_t scores_stride, int32_t base_capacity,
                         double floor_ratio, int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens,
                         int32_t* cu_klen, int32_t* cu_headlens, int32_t* host_mirror, int32_t host_seq, void* ws, size_t ws_bytes,
                         pkv_stream_t stream);
@@ -184,7 +186,7 @@ int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores,
  * thing - every head's ADAPTIVE list (:709-711: sorted scores x sum(top base)/sum(all), model dtype), first M entries.
  * lists_out: dtype [H][M] for this rank's H heads; after the all-gather every rank calls pkv_ada_budget(sorted_val = the
  * gathered lists, L = M, normalize = 0).  M >= min(S-w, H_total*base) keeps that exact (see pkv_ada_budget_topm). */
-int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t M, const void* scores, int64_t scores_stride,
+PKV_API int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t M, const void* scores, int64_t scores_stride,
                            const int32_t* top_idx, int64_t idx_stride, int32_t base_capacity, int32_t normalize,
                            void* lists_out, void* ws, size_t ws_bytes, pkv_stream_t stream);
 
@@ -194,7 +196,7 @@ int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t M, const
  * HeadKV: given_capacity = device int32 [H] (host-derived, :855), M >= max capacity; writes head_lens, cu_klen only.
  * The host then reads the capacities back (klen_sum / max_seqlen_k are Python ints at the boundary, :685-686; the
  * reference has the same sync at :718) and calls pkv_gather_flat(top_idx, idx_stride = M, ...).  ws: pkv_workspace_bytes(d). */
-int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base_capacity, double floor_ratio,
+PKV_API int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base_capacity, double floor_ratio,
                    int32_t normalize, const int32_t* given_capacity, int32_t* top_idx, int32_t* head_capacity,
                    int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens /* [H] inclusive prefix (:687), may be NULL */,
                    int32_t* host_mirror /* may be NULL: device-visible PINNED HOST int32 [H+1]; the budget kernel stores the
@@ -204,7 +206,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
 
 /* Var-len metadata (:682-698) from head_capacity: head_lens[H] = cap_h + w, cu_klen[H+1]
  * (exclusive prefix + total).  All device int32. */
-int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, int32_t* head_lens,
+PKV_API int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, int32_t* head_lens,
                      int32_t* cu_klen, pkv_stream_t stream);
 
 /* Flat gather (:733-757): for head h rows sorted_idx[h][0..cap_h) then the window tail, written at
@@ -212,14 +214,14 @@ int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, in
  * bound on max_h cap_h (sizes the launch); 0 = unknown (S-w).  out_rows = rows k_out / v_out hold (> 0: nothing is
  * stored at or beyond it - the outputs may be sized by a bound before the capacities are known on the host; 0 = not
  * checked). */
-int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32_t* sorted_idx,
+PKV_API int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32_t* sorted_idx,
                     int64_t idx_stride, const int32_t* head_capacity, const int32_t* cu_klen,
                     void* k_out, void* v_out, int64_t out_rows, pkv_stream_t stream);
 
 /* Decode-time flat-cache append (csrc/csrc/cuda_api.cu:11-85 update_flatten_view): out has
  * origin_rows + H rows; head h: copy head_lens[h] rows from cache row cu_klen[h] to out row
  * cu_klen[h]+h, then state[h] at out row cu_klen[h+1]+h.  head_dim elements of dtype per row. */
-int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const void* cache,
+PKV_API int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const void* cache,
                             const void* state, const int32_t* head_lens, const int32_t* cu_klen,
                             void* out, pkv_stream_t stream);
 
@@ -232,27 +234,30 @@ int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, const vo
  * RCCL already loaded in the process - PyTorch's, or the one named by PKV_RCCL_LIB, else librccl.so.1).
  * PyTorch does not expose its communicator, so the Python host issues the same collective through torch.distributed
  * (pyramidkv_amd/dist.py); a C/C++ host calls this. */
-int pkv_allgather_indices(void* nccl_comm, const int32_t* idx_local, int32_t* idx_all, int32_t B, int32_t H_local,
+PKV_API int pkv_allgather_indices(void* nccl_comm, const int32_t* idx_local, int32_t* idx_all, int32_t B, int32_t H_local,
                           int32_t k, void* ws, size_t ws_bytes, pkv_stream_t stream);
-int pkv_last_nccl_error(void); /* ncclResult_t of the last PKV_ERR_COLLECTIVE on this thread */
+PKV_API int pkv_last_nccl_error(void); /* ncclResult_t of the last PKV_ERR_COLLECTIVE on this thread */
 
 /* ---- per-kernel device timing (hipEvent pairs on `stream`), used by bench.py ---- */
 enum pkv_kernel_id {
   PKV_K_LOGITS = 0, PKV_K_FINALIZE = 1, PKV_K_TOPK = 2, PKV_K_GATHER = 3, PKV_K_H2O_STATS = 4,
   PKV_K_H2O_COLSUM = 5, PKV_K_SORT = 6, PKV_K_BUDGET = 7, PKV_K_COUNT = 8
 };
-int pkv_prof_enable(int on);                                   /* returns previous state */
-int pkv_prof_read(double* ms_sum, int64_t* launches, int reset); /* arrays of PKV_K_COUNT; syncs events */
+PKV_API int pkv_prof_enable(int on);                                   /* returns previous state */
+PKV_API int pkv_prof_read(double* ms_sum, int64_t* launches, int reset); /* arrays of PKV_K_COUNT; syncs events */
 
 /* ---- debug / test hooks (not part of the drop-in surface) ----
  * The trace hooks and the PKV_LOGITS_ABLATE measurement knob exist only in the -DPKV_DEBUG build (libpkv_debug.so,
  * `make -C pyramidkv_amd/csrc debug`); the release library returns PKV_ERR_UNSUPPORTED for a non-NULL buffer and
  * never reads the environment variable. */
-int pkv_debug_build(void);                    /* 1 = this library was built with -DPKV_DEBUG */
-int pkv_debug_topk_trace(void* device_u64x8); /* NULL disables; row 0 of every later top-k launch stamps 7 phase clocks */
-int pkv_debug_wg_trace(void* device_u64);     /* NULL disables; 2*262144 u64: per-workgroup (start,end) wall clock, 100 MHz */
-int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream); /* the kernels' exp(), for accuracy tests */
-int pkv_debug_round(int32_t dtype, const float* in, void* out, int64_t n, pkv_stream_t stream); /* fp32 -> dtype rounding used at every rounding point */
+PKV_API int pkv_debug_build(void);                    /* 1 = this library was built with -DPKV_DEBUG */
+PKV_API int pkv_debug_topk_trace(void* device_u64x8); /* NULL disables; row 0 of every later top-k launch stamps 7 phase clocks */
+PKV_API int pkv_debug_wg_trace(void* device_u64);     /* NULL disables; 2*262144 u64: per-workgroup (start,end) wall clock, 100 MHz */
+/* Test hooks of the RELEASE library (tests/test_gpu_parity.py): two element-wise kernels that expose device functions the
+ * hot kernels inline - the accurate exp() of finalize_kernel and the fp32 -> dtype rounding of every rounding point - so
+ * that the suite checks the shipped code, not a copy.  Nothing on the product path launches them (~2 KB of code). */
+PKV_API int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream);
+PKV_API int pkv_debug_round(int32_t dtype, const float* in, void* out, int64_t n, pkv_stream_t stream);
 
 #ifdef __cplusplus
 }
