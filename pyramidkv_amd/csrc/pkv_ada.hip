@@ -276,7 +276,7 @@ __device__ __forceinline__ void load_row_regs(const uint16_t* row, int L, int Lw
   for (int j = 0; j < NIT; ++j) {
     const int base = wave * Lw + j * 512 + lane * 8;
     if (j * 512 < Lw) {
-      if (vec && base + 8 <= ((L + 7) & ~7)) {
+      if (vec && base + 8 <= L) {                              // whole chunks only: a row may end at its last score (stride == L)
         raw[j].v = *reinterpret_cast<const uint4*>(row + (base < L ? base : 0));
       } else {
 #pragma unroll
@@ -474,11 +474,6 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st) {
   ws.list = p.list_ws ? reinterpret_cast<uint16_t*>(p.list_ws) : nullptr;       // [H][Lpad], 16-B aligned rows
   auto k_stats = dtype == 0 ? ada_stats_kernel<BF16> : ada_stats_kernel<F16>;
   auto k_lo = dtype == 0 ? ada_lo_kernel<BF16> : ada_lo_kernel<F16>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
   if (p.unsorted) {               // counts straight from the un-sorted score rows (no top-M list, no sort)
     if (dtype == 0) {
       hipLaunchKernelGGL(ada_stats_u_kernel<BF16>, dim3(p.H), dim3(TK_THREADS), 0, st, p, ws);
@@ -490,6 +485,11 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st) {
     hipLaunchKernelGGL(ada_final_kernel, dim3(1), dim3(256), 0, st, p, ws, omf, p.window, p.head_lens_out, p.cu_klen_out,
                        p.cu_headlens_out);
     return hipGetLastError();
+  }
+  if (lds > 48 * 1024) {                // the list kernels stage a whole list in LDS (the un-sorted kernels above use static LDS only)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_stats, dim3(p.H), dim3(256), lds, st, p, ws);
   if (p.adaptive_out) return hipGetLastError();

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(1024) void topk_f32_kernel(TopkParams p) {
   __shared__ uint32_t sh_digit, sh_kk, sh_cnt, wave_cnt[16], sh_taken;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = blockIdx.x, L = p.L;
-  const int k = p.k_per_row ? p.k_per_row[row] : p.k;
+  int k = p.k_per_row ? min(p.k_per_row[row], p.k) : p.k;      // a device-side capacity never exceeds the validated k (LDS list, output row)
+  if (k > L) k = L;
   if (k <= 0) return;
   const float* sc = reinterpret_cast<const float*>(p.scores) + (int64_t)row * p.scores_stride;
   uint32_t ureg[REG ? TKF_NV : 1];

@@ -116,6 +116,12 @@ def score_h2o(q, k, window: int, scale_mode: str = "div", kv_group: int = 1) -> 
     return out[..., :L]
 
 
+def topk_fits(rows: int, L: int, k: int) -> bool:
+    """True when a row of L scores and k winners fits ONE top-k workgroup (no long-row scratch): the only form that takes
+    ``k_per_row``."""
+    return N.lib.pkv_topk_workspace_bytes(rows, L, k) == 0
+
+
 def topk(scores: torch.Tensor, k: int, k_per_row: Optional[torch.Tensor] = None) -> torch.Tensor:
     """pyramidkv_utils.py:334.  scores [..., L] (16-bit) -> int32 [..., k], (value desc, index asc).  ``k_per_row`` (device
     int32, one entry per row, each <= k): row r gets only its first k_per_row[r] entries (the rest of the row is unspecified) -

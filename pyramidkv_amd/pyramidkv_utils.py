@@ -462,15 +462,18 @@ class AdaKVCluster(_FlatPolicy):
                 attn_score, self.base_capacity, self.floor_ratio, bool(self.normalize), self.window_size,   # :709-719, :682-691
                 host_mirror=mirror.t if mirror is not None else None, host_seq=mirror.next_seq() if mirror is not None else 0)
             caps = mirror.wait(key_states.device) if mirror is not None else _read_back(cap)   # the one host sync (:718)
-            try:
-                top_idx = ops.topk(attn_score, max(1, max(caps)), k_per_row=cap)
-            except ValueError:                                                       # beyond one workgroup's LDS
-                top_idx = None
-            if top_idx is not None:
-                return self._flat_from_capacity(key_states, value_states, top_idx, cap, num_heads, caps_host=caps,
-                                                meta=(head_lens, cu, cuh))
-            if key_states.dtype == torch.float32:
-                raise ValueError("Ada-SnapKV on fp32 tensors: head capacities up to 4096 past tokens")
+            kmax = max(1, max(caps))
+            if key_states.dtype == torch.float32 or ops.topk_fits(num_heads, L, kmax):
+                try:
+                    top_idx = ops.topk(attn_score, kmax, k_per_row=cap)
+                except ValueError:                                                   # fp32: capacities beyond 4096
+                    raise ValueError("Ada-SnapKV on fp32 tensors: head capacities up to 4096 past tokens") from None
+            else:
+                # rows / capacities beyond one top-k workgroup: the complete order once, the capacities already computed above
+                # (no second budget pass, no long-row top-k scratch for a call that cannot take k_per_row)
+                top_idx, _ = ops.sort_rows(attn_score, want_values=False)
+            return self._flat_from_capacity(key_states, value_states, top_idx, cap, num_heads, caps_host=caps,
+                                            meta=(head_lens, cu, cuh))
         sorted_idx, sorted_val = ops.sort_rows(attn_score)                           # :706
         cap = ops.ada_budget(sorted_val, self.base_capacity, self.floor_ratio, bool(self.normalize))  # :709-719
         return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads)

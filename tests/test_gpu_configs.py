@@ -667,6 +667,32 @@ def test_adakv_and_headkv_long_rows(P):
         assert off == kx.shape[0] == cl.klen_sum
 
 
+def test_adakv_capacity_beyond_one_topk_workgroup(P):
+    """Ada-SnapKV with H * base > 4096 whose largest head capacity does not fit one top-k workgroup (2 L + 4 k > 160 KB of LDS):
+    the budgets come from the un-sorted rows once, the order from the complete sort (no second budget pass, round 4).  Two heads
+    at S = 32768, base 26000, one of them peaky: capacities, metadata and flat K/V vs the oracle's arithmetic on the kernel's
+    own scores."""
+    S, H, w, cap = 32768, 2, 8, 26008
+    q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 7100)
+    q[:, 0] *= 3                                                      # head 0: sharp rows, few large scores
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    got_s = P.ops.score_window(qd, kd, w, "maxpool", 7, "mean").cpu()
+    sidx, caps = O.adakv_head_capacity(got_s, cap - w, 0.2, False)
+    per_head = [int(c) for c in caps[0]]
+    assert not P.ops.topk_fits(H, S - w, max(per_head)), per_head     # the case this test is about
+    ada = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=False)
+    kf, vf = ada.update_kv(kd, qd, vd)
+    assert ada.head_lens.cpu().tolist() == [c + w for c in per_head]
+    kx, vx, off = kf.cpu(), vf.cpu(), 0
+    for h in range(H):
+        n = per_head[h]
+        idx = sidx[0, h, :n]
+        assert torch.equal(kx[off:off + n], k[0, h, idx]) and torch.equal(vx[off:off + n], v[0, h, idx]), h
+        assert torch.equal(kx[off + n:off + n + w], k[0, h, -w:]) and torch.equal(vx[off + n:off + n + w], v[0, h, -w:]), h
+        off += n + w
+    assert off == kx.shape[0] == ada.klen_sum
+
+
 def test_merge_long_odd_prompt(P):
     """LOOK-M merge on a 40 001-token prompt (several 8192-pivot chunks per kept row, odd tail), un-expanded GQA 2, two
     batches: bit-identical to the oracle's merge of the same indices."""
