@@ -44,9 +44,9 @@ enum pkv_status {
   PKV_ERR_COLLECTIVE = -8   /* an RCCL call failed; see pkv_last_nccl_error() */
 };
 
-/* PKV_F32: pkv_score_window, pkv_topk(_ws), pkv_gather_compact, pkv_gather_streaming, pkv_gather_flat, pkv_compress,
- * pkv_select (window score), pkv_ada_budget_rows, pkv_ada_metadata and pkv_update_flatten_view only, D in {64,128},
- * topk <= 4096; every other entry point answers PKV_ERR_UNSUPPORTED (H2O and the merge in fp32). */
+/* PKV_F32: pkv_score_window, pkv_score_h2o, pkv_topk(_ws), pkv_gather_compact, pkv_gather_streaming, pkv_gather_flat,
+ * pkv_compress, pkv_compress_h2o, pkv_select, pkv_ada_budget_rows, pkv_ada_metadata and pkv_update_flatten_view, D in {64,128},
+ * topk <= 4096; every other entry point answers PKV_ERR_UNSUPPORTED. */
 enum pkv_dtype { PKV_BF16 = 0, PKV_F16 = 1, PKV_F32 = 2 };
 enum pkv_pool { PKV_POOL_NONE = 0, PKV_POOL_AVG = 1, PKV_POOL_MAX = 2 };
 enum pkv_reduce { PKV_REDUCE_SUM = 0, PKV_REDUCE_MEAN = 1 };

@@ -139,7 +139,7 @@ WsLayout ws_layout(const pkv_desc* d) {
   w.off_tk = o;      o = align_up(o + w.tk_bytes, 256);
   w.off_ada = o;     o = align_up(o + 1024 + (size_t)2 * d->H * 256 * 4, 256);                 // Ada-SnapKV budget scratch (pkv_ada_select)
   w.off_ada_list = o; o = align_up(o + (size_t)d->H * align_up((size_t)(d->topk > 0 ? d->topk : 1), 8) * 2, 256);   // looked-up top-M lists
-  w.off_rowstat = o; o = align_up(o + (size_t)d->B * d->H * d->S * sizeof(float), 256);    // H2O only: c_row of every query row
+  w.off_rowstat = o; o = align_up(o + (size_t)d->B * d->H * d->S * sizeof(float2), 256);   // H2O only: c_row of every query row (fp32 tensors: (max, 1/sum) pairs)
   w.off_knorm = o;   o = align_up(o + (size_t)d->B * d->H * 64 * sizeof(float), 256);       // H2O only: partial key-norm maxima
   w.total = o;
   return w;
@@ -192,7 +192,10 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     // stages per workgroup.  C <= 8 columns (expanded K/V, window 8): ONE stage per workgroup - measured in round 2 over
     // {1, 2, 3, 4, 8 stages}: 1 is the fastest at B = 1 (45.1-46.0 us against 45.7-48.6 us for 4 stages in the same
     // sessions; 2 and 3 stages are the slowest) and at B = 8 (350 vs 353 us): the in-workgroup pipeline only pays when few
-    // workgroups share a CU.  More columns per stage (un-expanded GQA K, C = 32): 4 workgroups per CU with 2..8 stages each
+    // workgroups share a CU.  Round 4 tried a chunk-WALKING grid (as many workgroups as the chip holds at once, each walking
+    // chunks blockIdx.x, + gridDim.x, ... with the next chunk's rows in flight): the loop costs 21 registers (one workgroup
+    // per CU less, or spills), C = 8: 44.7 -> 58.7 us at 4 per CU, C = 32: 19.95 -> 19.8 us; removed (gpurun_out r04_gqa).
+    // More columns per stage (un-expanded GQA K, C = 32): 4 workgroups per CU with 2..8 stages each
     // (one stage per workgroup costs +4 us there).  Round 3, after the logits stores moved one stage back (pkv_score.hip):
     // same ranking - C = 8: 44.3 us at 1 stage, 46.2 / 45.6 / 46.4 / 47.3 at 2 / 4 / 8 / 16; C = 32: 16.8 us at 2 stages
     // (1024 workgroups), 17.2 at 3, 17.3 at 4, 20.1 at 1 (profiles/r03/ab/defer_stores_ab.txt, one_stage_lds_direct_ab.txt).
@@ -249,6 +252,11 @@ int do_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores, 
   hp.scale_mode = d->scale_mode;
   hp.sqrt_d = (float)sqrt((double)d->D);
   hp.rcp_sqrt_d = 1.0f / hp.sqrt_d;
+  if (d->dtype == PKV_F32) {                                                 // both passes of the fp32 form (pkv_f32.hip)
+    ProfScope ps(PKV_K_H2O_COLSUM, st);
+    hipError_t e = launch_h2o_f32(hp, st);
+    return e == hipSuccess ? PKV_OK : hip_fail(e);
+  }
   {
     ProfScope ps(PKV_K_H2O_STATS, st);                                       // key-norm scan + statistics pass
     hipError_t e = launch_h2o_knorm(d->dtype, hp, st);
@@ -351,7 +359,7 @@ int do_gather(const GatherParams& g, int max_rows, hipStream_t st) {
 
 int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
                     void* v_out, int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
-  int rc = check_desc(d, true, true, !h2o);
+  int rc = check_desc(d, true, true, true);
   if (rc) return rc;
   if (!q || !k || !v || !k_out || !v_out || !ws) return PKV_ERR_NULL;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out) || misaligned(ws))
@@ -418,7 +426,7 @@ int pkv_score_window(const pkv_desc* d, const void* q, const void* k, void* scor
 
 int pkv_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores_out,
                   int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream) {
-  int rc = check_desc(d, false);
+  int rc = check_desc(d, false, true, true);
   if (rc) return rc;
   if (!q || !k || !scores_out || !ws) return PKV_ERR_NULL;
   if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
@@ -484,7 +492,7 @@ int pkv_compress_h2o(const pkv_desc* d, const void* q, const void* k, const void
 // ---- selection only (score -> top-k), the front half of pkv_compress: what the merge path needs ----
 int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int32_t* idx_out, void* ws, size_t ws_bytes,
                pkv_stream_t stream) {
-  int rc = check_desc(d, true, true, !h2o);
+  int rc = check_desc(d, true, true, true);
   if (rc) return rc;
   if (!q || !k || !idx_out || !ws) return PKV_ERR_NULL;
   if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
@@ -511,7 +519,7 @@ MergeWs merge_ws(const pkv_desc* d) {
   m.off_n = o;     o = align_up(o + 4, 256);
   m.off_drop = o;  o = align_up(o + (size_t)d->S * 4, 256);
   m.off_pivot = o; o = align_up(o + (size_t)d->B * d->H * d->S * 4, 256);
-  m.off_tn = o;    o = align_up(o + (size_t)d->B * d->H * m.ntp * d->D * 2, 256);
+  m.off_tn = o;    o = align_up(o + (size_t)d->B * d->H * m.ntp * d->D * (d->dtype == PKV_F32 ? 4 : 2), 256);
   m.off_start = o; o = align_up(o + (size_t)d->B * d->H * (d->topk + d->window + 1) * 4, 256);
   m.off_list = o;  o = align_up(o + (size_t)d->B * d->H * d->S * 4, 256);
   m.total = o;
@@ -526,7 +534,7 @@ size_t pkv_merge_workspace_bytes(const pkv_desc* d) {
 
 int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx, int64_t idx_stride,
                       void* k_out, void* v_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
-  int rc = check_desc(d, true, false);
+  int rc = check_desc(d, true, false, true);
   if (rc) return rc;
   if (!k || !v || !idx || !k_out || !v_out || !ws) return PKV_ERR_NULL;
   if (misaligned(k) || misaligned(v) || misaligned(k_out) || misaligned(v_out) || misaligned(ws)) return PKV_ERR_ALIGN;

@@ -522,4 +522,116 @@ hipError_t launch_topk_f32(int rows, const TopkParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// H2O on fp32 tensors (reference pyramidkv_utils.py:544-554 is dtype-generic; round 4).  The same two passes as the 16-bit
+// kernels (pkv_h2o.hip) without any rounding to a model dtype, on v_mfma_f32_16x16x4_f32 (1/16 of the bf16 matrix rate:
+// built for completeness, S x S x D fp32 flops are what they are):
+//   h2o_stats_f32_kernel   per query row: (max, 1 / sum exp) over all keys; one wave = 16 resident query rows, keys streamed
+//   h2o_colsum_f32_kernel  per key column: sum over all query rows of exp(x - max) * (1 / sum); one wave = 16 resident keys
+// Operand layout as in logits_f32_kernel: lane (l % 16 = row / column, l / 16 = which float4 of every 16 elements).
+// The fp32 sums (dot product, softmax denominator, column sum) are not pinned to an order by the reference: tests compare
+// the scores with a relative tolerance, selections up to score ties within it.
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ void load_row_f32(f32x4 (&f)[KS], const float* base, int64_t row, int64_t stride, int lg) {
+  const float* r = base + row * stride + 4 * lg;
+#pragma unroll
+  for (int j = 0; j < KS; ++j) f[j] = *reinterpret_cast<const f32x4*>(r + 16 * j);
+}
+template <int KS>
+__device__ __forceinline__ f32x4 dot16_f32(const f32x4 (&a)[KS], const f32x4 (&b)[KS]) {     // D[a row][b column]
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < KS; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], b[j][i], acc, 0, 0, 0);
+  return acc;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void h2o_stats_f32_kernel(H2OParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
+  const int S = p.S, L = S - p.w;
+  const float* qb = reinterpret_cast<const float*>(p.q) + (int64_t)b * p.qs_b + (int64_t)h * p.qs_h;
+  const float* kb = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
+  const int qi = blockIdx.x * 64 + wave * 16 + li;                         // this lane's query (column of D)
+  f32x4 qf[KS];
+  load_row_f32<KS>(qf, qb, qi < S ? qi : S - 1, p.qs_s, lg);
+  const float fmin_v = -3.4028234663852886e38f;                            // torch.finfo(torch.float32).min
+  float m = -INFINITY, z = 0.f;
+  for (int s0 = 0; s0 < S; s0 += 16) {
+    f32x4 kf[KS];
+    load_row_f32<KS>(kf, kb, s0 + li < S ? s0 + li : S - 1, p.ks_s, lg);
+    const f32x4 acc = dot16_f32<KS>(kf, qf);                               // D[key s0 + 4*lg + r][query qi]
+    float x[4], mx = m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = s0 + 4 * lg + r;
+      float v = p.scale_mode == 0 ? div_const(acc[r], p.sqrt_d, p.rcp_sqrt_d) : acc[r] * p.rcp_sqrt_d;   // / math.sqrt(head_dim) (:544)
+      if (qi >= L && s >= L && (s - L) > (qi - L)) v = v + fmin_v;        // the last w x w corner (:545-551)
+      x[r] = s < S ? v : -INFINITY;
+      mx = fmaxf(mx, x[r]);
+    }
+    if (mx > m) { z = (m == -INFINITY) ? 0.f : z * pkv_exp(m - mx); m = mx; }
+    if (m != -INFINITY) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z += pkv_exp(x[r] - m);
+    }
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {                                     // the four key groups of the lane's query
+    const float mo = __shfl_xor(m, o, 64), zo = __shfl_xor(z, o, 64);
+    const float M = fmaxf(m, mo), Ms = (M == -INFINITY) ? 0.f : M;
+    z = z * pkv_exp(m - Ms) + zo * pkv_exp(mo - Ms);
+    m = M;
+  }
+  if (lg == 0 && qi < S) reinterpret_cast<float2*>(p.rowstat)[(int64_t)bh * S + qi] = make_float2(m, 1.0f / z);   // ATen CPU softmax: exp(x - max) * (1 / sum)
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void h2o_colsum_f32_kernel(H2OParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
+  const int S = p.S, L = S - p.w;
+  const float* qb = reinterpret_cast<const float*>(p.q) + (int64_t)b * p.qs_b + (int64_t)h * p.qs_h;
+  const float* kb = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
+  const float2* rs = reinterpret_cast<const float2*>(p.rowstat) + (int64_t)bh * S;
+  const int kj = blockIdx.x * 64 + wave * 16 + li;                         // this lane's key (column of D); columns >= L are not stored
+  f32x4 kf[KS];
+  load_row_f32<KS>(kf, kb, kj < S ? kj : S - 1, p.ks_s, lg);
+  float sum = 0.f;
+  for (int i0 = 0; i0 < S; i0 += 16) {
+    f32x4 qf[KS];
+    load_row_f32<KS>(qf, qb, i0 + li < S ? i0 + li : S - 1, p.qs_s, lg);
+    const f32x4 acc = dot16_f32<KS>(qf, kf);                               // D[query i0 + 4*lg + r][key kj]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * lg + r;
+      const float2 st = rs[i < S ? i : S - 1];
+      const float v = p.scale_mode == 0 ? div_const(acc[r], p.sqrt_d, p.rcp_sqrt_d) : acc[r] * p.rcp_sqrt_d;
+      const float pr = pkv_exp(v - st.x) * st.y;                           // fp32 softmax (:553); keys < L never touch the masked corner
+      sum += i < S ? pr : 0.f;                                             // fp32 column sum (:554)
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  if (lg == 0 && kj < L) reinterpret_cast<float*>(p.scores)[(int64_t)bh * p.scores_stride + kj] = sum;
+}
+
+hipError_t launch_h2o_f32(const H2OParams& p, hipStream_t st) {
+  dim3 g1((p.S + 63) / 64, p.B * p.H), g2((p.S - p.w + 63) / 64, p.B * p.H);
+  if (p.D == 64) {
+    hipLaunchKernelGGL(h2o_stats_f32_kernel<4>, g1, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(h2o_colsum_f32_kernel<4>, g2, dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(h2o_stats_f32_kernel<8>, g1, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(h2o_colsum_f32_kernel<8>, g2, dim3(256), 0, st, p);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace pkv

@@ -218,6 +218,7 @@ hipError_t launch_logits_f32(const LogitsParams& p, hipStream_t st);
 hipError_t launch_finalize_f32(const FinalizeParams& p, hipStream_t st);
 hipError_t launch_topk_f32(int rows, const TopkParams& p, hipStream_t st);
 int topk_f32_max_k();
+hipError_t launch_h2o_f32(const H2OParams& p, hipStream_t st);            // fp32 tensors (pkv_f32.hip): rowstat = float2 (max, 1/sum) per row
 hipError_t launch_h2o_knorm(int dtype, const H2OParams& p, hipStream_t st);
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st);
 hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st);

@@ -446,6 +446,196 @@ hipError_t launch_merge_t(const MergeParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 tensors (round 4; the reference's merge_kv is dtype-generic): the same six steps without any rounding to a model
+// dtype.  mark / droplist / bucket are shared; targets, pivot and scatter have fp32 forms on v_mfma_f32_16x16x4_f32 and
+// plain fp32 arithmetic.  Built for completeness (the matrix pipe runs fp32 at 1/16 of its bf16 rate): no LDS tiling of the
+// kept rows - they are read from the L2-resident unit-norm buffer.  The fp32 dot products are not pinned to an order by the
+// reference: a dropped row whose two best similarities agree to ~1e-7 may choose the other kept row (tests allow that).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float mf32x4;
+
+template <int KSF>                                                         // float4 pieces per lane and row: D / 16
+__global__ __launch_bounds__(256) void merge_targets_f32_kernel(MergeParams p) {
+  constexpr int D = KSF * 16, EPL = D / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= p.k + p.w) return;
+  const int32_t* idx_row = p.idx + (int64_t)bh * p.idx_stride;
+  const int pos = key_target_pos(p, idx_row, j);
+  const float* src = reinterpret_cast<const float*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h + (int64_t)pos * p.ks_s + lane * EPL;
+  float x[EPL], sq = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { x[e] = src[e]; sq += x[e] * x[e]; }
+  const float n2 = wave_sum(sq);
+  const float n = sqrtf(n2);                                               // torch.norm
+  if (lane == 0 && (!(n2 < INFINITY) || !(n > 0.f))) atomicOr(p.kept_bad + bh, 1);
+  float* dst = reinterpret_cast<float*>(p.tn) + ((int64_t)bh * p.ntp + j) * D + lane * EPL;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) dst[e] = x[e] / n;                         // k / norm
+}
+
+// order-preserving 32-bit key of an fp32 similarity; NaN ranks above everything (torch.max propagates the first NaN)
+__device__ __forceinline__ uint32_t sim_key_f32(float x) {
+  if (x != x) return 0xffffffffu;
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int KSF>
+__global__ __launch_bounds__(256) void merge_pivot_f32_kernel(MergeParams p) {
+  constexpr int D = KSF * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
+  const int n = *p.ndrop;
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  if (blockIdx.x * 64 >= n) return;
+  const int nt = p.k + p.w;
+  const float* kbase = reinterpret_cast<const float*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
+  const float* tn = reinterpret_cast<const float*>(p.tn) + (int64_t)bh * p.ntp * D;
+  // A operand: dropped row row0 + li (clamped), unit-normalised in registers
+  mf32x4 af[KSF];
+  {
+    const int r = row0 + li < n ? row0 + li : n - 1;
+    const float* row = kbase + (int64_t)p.drop[r] * p.ks_s + 4 * lg;
+    float n2 = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < KSF; ++jj) {
+      af[jj] = *reinterpret_cast<const mf32x4*>(row + 16 * jj);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) n2 += af[jj][i] * af[jj][i];
+    }
+    n2 += __shfl_xor(n2, 16, 64);
+    n2 += __shfl_xor(n2, 32, 64);
+    const float nr = sqrtf(n2);
+#pragma unroll
+    for (int jj = 0; jj < KSF; ++jj)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[jj][i] = af[jj][i] / nr;
+  }
+  // lane holds rows 4*lg + r of the wave's 16 and column li of every 16-target tile: strictly-greater updates keep the FIRST
+  // maximum of the lane's columns; the final reduction over the 16 lanes prefers the smaller column on equal keys
+  uint32_t bestk[4] = {0u, 0u, 0u, 0u};
+  int bestc[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  for (int t0 = 0; t0 < nt; t0 += 16) {
+    const int col = t0 + li;
+    mf32x4 bf[KSF];
+    const float* trow = tn + (int64_t)(col < nt ? col : nt - 1) * D + 4 * lg;
+#pragma unroll
+    for (int jj = 0; jj < KSF; ++jj) bf[jj] = *reinterpret_cast<const mf32x4*>(trow + 16 * jj);
+    mf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < KSF; ++jj)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[jj][i], bf[jj][i], acc, 0, 0, 0);   // D[dropped row][kept row]
+    if (col < nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t key = sim_key_f32(acc[r]);
+        if (key > bestk[r] || bestc[r] == 0x7fffffff) { bestk[r] = key; bestc[r] = col; }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    uint32_t kx = bestk[r];
+    int cx = bestc[r];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const uint32_t ko = (uint32_t)__shfl_xor((int)kx, o, 64);
+      const int co = __shfl_xor(cx, o, 64);
+      if (ko > kx || (ko == kx && co < cx)) { kx = ko; cx = co; }
+    }
+    const int row = row0 + lg * 4 + r;
+    if (li == 0 && row < n) p.pivot[(int64_t)bh * p.S + row] = cx;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(2 * D) void merge_scatter_f32_kernel(MergeParams p) {
+  constexpr int NTH = 2 * D, NW = NTH / 64;                                // one element per thread: D threads for K, D for V
+  extern __shared__ __attribute__((aligned(16))) uint32_t ms_bitmap_f32[];
+  __shared__ int32_t lst[MS_CAP];
+  __shared__ int32_t wsum[NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = tid % D, is_v = tid / D;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
+  const int j = blockIdx.x;
+  const int nt = p.k + p.w;
+  const int32_t* idx_row = p.idx + (int64_t)bh * p.idx_stride;
+  const int32_t* start = p.bstart + (int64_t)bh * (nt + 1);
+  const int beg = start[j], m = start[j + 1] - beg;
+  const int32_t* group = p.blist + (int64_t)bh * p.S + beg;
+  const float* base = is_v ? reinterpret_cast<const float*>(p.vptr) + (int64_t)b * p.vs_b + (int64_t)hk * p.vs_h
+                           : reinterpret_cast<const float*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
+  const int64_t sstride = is_v ? p.vs_s : p.ks_s;
+  const int tpos = is_v ? val_target_pos(p, idx_row, j) : key_target_pos(p, idx_row, j);
+  const float t = base[(int64_t)tpos * sstride + d];                      // the kept row BEFORE merging (gather at :157/:160)
+  float acc = t;                                                           // include_self
+  if (m > 0) {                                                             // workgroup-uniform
+    const int nw = (p.S + 31) >> 5;
+    for (int wd = tid; wd < nw; wd += NTH) ms_bitmap_f32[wd] = 0u;
+    __syncthreads();
+    for (int e = tid; e < m; e += NTH) { const int s = group[e]; atomicOr(&ms_bitmap_f32[s >> 5], 1u << (s & 31)); }
+    __syncthreads();
+    const int wpt = (nw + NTH - 1) / NTH;
+    const int w0 = min(nw, tid * wpt), w1 = min(nw, w0 + wpt);
+    int pc = 0;
+    for (int wd = w0; wd < w1; ++wd) pc += __popc(ms_bitmap_f32[wd]);
+    int incl = pc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) woff += w2 < wave ? wsum[w2] : 0;
+    const int first = woff + incl - pc;
+    for (int pass0 = 0; pass0 < m; pass0 += MS_CAP) {
+      int r = first;
+      for (int wd = w0; wd < w1 && r < pass0 + MS_CAP; ++wd) {
+        uint32_t bits = ms_bitmap_f32[wd];
+        const int c = __popc(bits);
+        if (r + c <= pass0) { r += c; continue; }
+        while (bits) {
+          const int bpos = __builtin_ctz(bits);
+          bits &= bits - 1;
+          if (r >= pass0 && r < pass0 + MS_CAP) lst[r - pass0] = wd * 32 + bpos;
+          ++r;
+        }
+      }
+      __syncthreads();
+      const int mm = min(MS_CAP, m - pass0);
+      for (int e0 = 0; e0 < mm; e0 += 8) {                                 // ascending order, 8 row loads in flight
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = base[(int64_t)lst[e0 + u < mm ? e0 + u : mm - 1] * sstride + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (e0 + u < mm) acc += (x[u] + t) / 2.0f;                       // (x + t) / 2 (:158), fp32 accumulation in ascending order
+      }
+      __syncthreads();
+    }
+  }
+  float* out = reinterpret_cast<float*>(is_v ? p.v_out : p.k_out) + ((int64_t)bh * nt + j) * D + d;
+  *out = acc / (float)(1 + m);                                             // scatter_reduce(mean, include_self) (:159-162)
+}
+
+template <int KSF>
+hipError_t launch_merge_f32_t(const MergeParams& p, hipStream_t st) {
+  constexpr int D = KSF * 16;
+  const int nt = p.k + p.w;
+  const dim3 gt((nt + 3) / 4, p.B * p.H), gp((p.S + 63) / 64, p.B * p.H), gs(nt, p.B * p.H);
+  const size_t bitmap_bytes = (size_t)((p.S + 31) / 32) * 4;
+  hipLaunchKernelGGL((merge_targets_f32_kernel<KSF>), gt, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((merge_pivot_f32_kernel<KSF>), gp, dim3(256), 0, st, p);
+  hipLaunchKernelGGL(merge_bucket_kernel, dim3(p.B * p.H), dim3(1024), 0, st, p);
+  hipLaunchKernelGGL((merge_scatter_f32_kernel<D>), gs, dim3(2 * D), bitmap_bytes, st, p);
+  return hipGetLastError();
+}
+
 size_t merge_max_seq() { return 49152u * 8u; }    // the scatter kernel's position bitmap (one bit per position): 48 KB of dynamic LDS
 
 hipError_t launch_merge(int dtype, const MergeParams& p, hipStream_t st) {
@@ -456,6 +646,7 @@ hipError_t launch_merge(int dtype, const MergeParams& p, hipStream_t st) {
   const int mb = (int)std::min<int64_t>((total + 255) / 256, 1024);
   hipLaunchKernelGGL(merge_mark_kernel, dim3(mb), dim3(256), 0, st, p);
   hipLaunchKernelGGL(merge_droplist_kernel, dim3(1), dim3(1024), 0, st, p);
+  if (dtype == 2) return p.D == 64 ? launch_merge_f32_t<4>(p, st) : launch_merge_f32_t<8>(p, st);     // fp32: head sizes 64 / 128
   if (dtype == 0) {
     if (p.D == 64) return launch_merge_t<BF16, 2>(p, st);
     if (p.D == 256) return launch_merge_t<BF16, 8>(p, st);

@@ -68,7 +68,7 @@ def test_strerror_and_argument_validation_without_gpu(P):
     d.dtype = 2
     assert N.lib.pkv_workspace_bytes(d) > ws16                  # 4-byte logits and scores
     assert N.lib.pkv_compress(d, None, 16, 16, 16, 16, None, 16, 1 << 30, None) == -7        # descriptor accepted, null q
-    assert N.lib.pkv_compress_h2o(d, 16, 16, 16, 16, 16, None, 16, 1 << 30, None) == -5
+    assert N.lib.pkv_compress_h2o(d, None, 16, 16, 16, 16, None, 16, 1 << 30, None) == -7    # H2O takes fp32 since round 4
     d.k_stride[2] = 130                                        # fp32 rows: multiples of 4 elements
     assert N.lib.pkv_gather_streaming(d, 16, 16, 16, 16, None) == -3
     d.k_stride[2] = 132
@@ -92,7 +92,11 @@ def test_strerror_and_argument_validation_without_gpu(P):
     m.D = 256
     assert N.lib.pkv_merge_workspace_bytes(m) > need64 and mc() == -4
     m.dtype = 2
-    assert mc() == -5                                                   # fp32 merge
+    assert mc() == -5                                                   # fp32 merge: head sizes 64 / 128 only (D is 256 here)
+    m.D = 128
+    for i in range(3):
+        m.k_stride[i] = m.v_stride[i] = m.q_stride[i] = 128
+    assert mc() == -4                                                   # fp32 merge accepted since round 4: only the workspace is short
     m.dtype, m.D, m.S = 1, 128, 393217
     assert mc() == -5                                                   # longer than the position bitmap
     m.S, m.topk = 200000, 65530
