@@ -29,9 +29,47 @@ def _require_gpu(*ts):
 
 def _rowmajor(t: torch.Tensor) -> torch.Tensor:
     """[B,H,S,D] with D contiguous and 16-byte aligned rows; anything else is materialised."""
+    if t.is_contiguous() and not (t.shape[-1] & 7) and not (t.data_ptr() & 15):      # the common case, one cheap test
+        return t
     if t.stride(-1) != 1 or any(s % 8 for s in t.stride()[:-1]) or t.data_ptr() % 16:
         t = t.contiguous()
     return t
+
+
+class _DeviceGuard:
+    """``with torch.cuda.device(d)`` without its cost when ``d`` is already current (the usual case: ~4 us per call saved;
+    at S <= 8192 one update_kv is bound by the host's time to issue it, bench.py `sweep[].host_us`)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device: torch.device):
+        self.idx = device.index
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if self.idx is not None and cur != self.idx:
+            torch.cuda.set_device(self.idx)
+            self.prev = cur
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+            self.prev = -1
+        return False
+
+
+def _workspace_and_stream(nbytes: int, device: torch.device):
+    """(scratch, raw stream handle) of the CURRENT stream of ``device`` - one ``current_stream`` query for both."""
+    st = torch.cuda.current_stream(device).cuda_stream
+    key = (device.index if device.index is not None else torch.cuda.current_device(), st)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _WS_RETIRED.setdefault(key, []).append(ws)     # never trimmed: a captured graph may still replay with this address
+        ws = torch.empty(max(nbytes, 2 * ws.numel() if ws is not None else 0, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws, st
 
 
 def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
@@ -39,15 +77,7 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     supersedes is kept alive (``_WS_RETIRED``), because a HIP graph captured while it was current replays with its
     address.  Capture a graph only after one eager call of the same shape on the same stream (the workspace then exists
     outside the graph's private pool); see INTEGRATION.md."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        if ws is not None:
-            _WS_RETIRED.setdefault(key, []).append(ws)     # never trimmed: a captured graph may still replay with this address
-        ws = torch.empty(max(nbytes, 2 * ws.numel() if ws is not None else 0, 1 << 20), dtype=torch.uint8, device=device)
-        _WS[key] = ws
-    return ws
+    return _workspace_and_stream(nbytes, device)[0]
 
 
 def release_workspaces() -> None:
@@ -78,6 +108,23 @@ def make_desc(q: Optional[torch.Tensor], k: torch.Tensor, v: Optional[torch.Tens
     d.scale_mode = N.SCALE[scale_mode]
     d.topk = topk
     return d
+
+
+_DESC_CACHE: dict = {}
+
+
+def _scoring_desc(q, k, v, window, pooling, kernel_size, reduce, scale_mode, topk, kv_group):
+    """(descriptor, pkv_workspace_bytes(descriptor)) for a scoring call, cached by everything the descriptor is made of:
+    filling the ctypes struct and asking the library for the scratch size are ~5 us of host time per call otherwise."""
+    key = (k.dtype, q.shape, k.shape, q.stride(), k.stride(), v.stride() if v is not None else None, window, pooling, kernel_size,
+           reduce, scale_mode, topk, kv_group)
+    hit = _DESC_CACHE.get(key)
+    if hit is None:
+        if len(_DESC_CACHE) > 4096:
+            _DESC_CACHE.clear()
+        d = make_desc(q, k, v, window, pooling, kernel_size, reduce, scale_mode, topk, kv_group)
+        hit = _DESC_CACHE[key] = (d, N.lib.pkv_workspace_bytes(d))
+    return hit
 
 
 def _lp(L: int) -> int:
@@ -191,9 +238,9 @@ def compress(q, k, v, window: int, topk_k: int, pooling, kernel_size: int, scale
     _require_gpu(q, k, v)
     q, k, v = _rowmajor(q), _rowmajor(k), _rowmajor(v)
     B, H, S, D = q.shape
-    with torch.cuda.device(k.device):
-        d = make_desc(q, k, v, window, None if h2o else pooling, kernel_size, "sum", scale_mode, topk_k, kv_group)
-        ws = workspace(N.lib.pkv_workspace_bytes(d), k.device)
+    with _DeviceGuard(k.device):
+        d, nb = _scoring_desc(q, k, v, window, None if h2o else pooling, kernel_size, "sum", scale_mode, topk_k, kv_group)
+        ws, st = _workspace_and_stream(nb, k.device)
         ko = torch.empty(B, H, topk_k + window, D, dtype=k.dtype, device=k.device)
         vo = torch.empty_like(ko)
         if idx_out is not None:
@@ -202,9 +249,10 @@ def compress(q, k, v, window: int, topk_k: int, pooling, kernel_size: int, scale
         else:
             idx = torch.empty(B, H, topk_k, dtype=torch.int32, device=k.device) if return_indices else None
         fn = N.lib.pkv_compress_h2o if h2o else N.lib.pkv_compress
-        N.check(fn(d, q.data_ptr(), k.data_ptr(), v.data_ptr(), ko.data_ptr(), vo.data_ptr(),
-                   idx.data_ptr() if idx is not None else None, ws.data_ptr(), ws.numel(), N.stream_ptr()),
-                "pkv_compress")
+        rc = fn(d, q.data_ptr(), k.data_ptr(), v.data_ptr(), ko.data_ptr(), vo.data_ptr(),
+                idx.data_ptr() if idx is not None else None, ws.data_ptr(), ws.numel(), st)
+        if rc:
+            N.check(rc, "pkv_compress")
     return (ko, vo, idx) if return_indices else (ko, vo)
 
 
