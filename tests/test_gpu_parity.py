@@ -491,6 +491,29 @@ def test_pyramid_layers_and_branches(P):
     assert kc is k3 and vc is v3
 
 
+def test_cluster_index_out_receives_the_selected_indices(P):
+    """``cluster.index_out`` (round 4; what bench.py and a head-sharded host use): update_kv also leaves its selected indices
+    in the caller's int32 [B,H,k] tensor - the indices of the one-call path, K/V unchanged - for expanded and un-expanded K/V."""
+    S, w, cap = 2048, 8, 128
+    q, k, v = make_qkv(2, 8, S, 128, "bf16", "gauss", 61)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    for cl, kk in ((P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool"), cap - w),
+                   (P.PyramidKVCluster(num_hidden_layers=32, layer_idx=5, window_size=w, max_capacity_prompt=cap, kernel_size=7,
+                                       pooling="maxpool"), None)):
+        if kk is None:
+            kk = cl.layer_budget(S)[1]
+        for g in (1, 4):
+            ks, vs = (kd, vd) if g == 1 else (kd[:, ::g].contiguous(), vd[:, ::g].contiguous())
+            kc0, vc0, idx0 = P.ops.compress(qd, ks, vs, w, kk, "maxpool", 7, kv_group=g, return_indices=True)
+            buf = torch.full((2, 8, kk), -1, dtype=torch.int32, device=DEV)
+            cl.index_out = buf
+            kc, vc = cl.update_kv(ks, qd, vs, None, 1 if g > 1 else 1)
+            cl.index_out = None
+            assert torch.equal(buf, idx0) and torch.equal(kc, kc0) and torch.equal(vc, vc0)
+    kc, vc = cl.update_kv(kd, qd, vd, None, 1)                   # and without a sink nothing else changes
+    assert kc.shape == (2, 8, kk + w, 128)
+
+
 def test_h2o_cluster(P):
     S, w, cap = 1024, 8, 64
     q, k, v = make_qkv(1, 4, S, 128, "bf16", "gauss", 55)
