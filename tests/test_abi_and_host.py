@@ -32,6 +32,13 @@ def test_header_symbols_exported(P):
         assert hasattr(lib, name), f"{name} declared in include/pkv.h but not exported by libpkv.so"
     assert set(P._native.EXPORTED) == declared
     assert lib.pkv_version() == 100
+    # hidden visibility + export map: the dynamic symbol table is the C ABI and nothing else
+    import shutil
+    import subprocess
+    if shutil.which("nm"):
+        out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "pyramidkv_amd", "libpkv.so")], capture_output=True, text=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+        assert exported == declared, sorted(exported ^ declared)[:10]
 
 
 def test_strerror_and_argument_validation_without_gpu(P):
