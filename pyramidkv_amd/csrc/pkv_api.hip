@@ -194,7 +194,9 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     // sessions; 2 and 3 stages are the slowest) and at B = 8 (350 vs 353 us): the in-workgroup pipeline only pays when few
     // workgroups share a CU.  Round 4 tried a chunk-WALKING grid (as many workgroups as the chip holds at once, each walking
     // chunks blockIdx.x, + gridDim.x, ... with the next chunk's rows in flight): the loop costs 21 registers (one workgroup
-    // per CU less, or spills), C = 8: 44.7 -> 58.7 us at 4 per CU, C = 32: 19.95 -> 19.8 us; removed (gpurun_out r04_gqa).
+    // per CU less, or spills), C = 8: 44.7 -> 58.7 us at 4 per CU, C = 32: 19.95 -> 19.8 us; and TWO stages of K rows in flight
+    // per workgroup (a second register set: 166 / 204 registers = one workgroup per CU less): C = 8: 44.6 -> 48.4 us, C = 32:
+    // 17.1 -> 21.0 us (19.2 with 4 stages per workgroup).  Both removed (profiles/r04/ab/).
     // More columns per stage (un-expanded GQA K, C = 32): 4 workgroups per CU with 2..8 stages each
     // (one stage per workgroup costs +4 us there).  Round 3, after the logits stores moved one stage back (pkv_score.hip):
     // same ranking - C = 8: 44.3 us at 1 stage, 46.2 / 45.6 / 46.4 / 47.3 at 2 / 4 / 8 / 16; C = 32: 16.8 us at 2 stages

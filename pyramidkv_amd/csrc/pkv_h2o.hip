@@ -99,20 +99,6 @@ template <typename T> struct Ones2;                   // two 1.0 of the model dt
 template <> struct Ones2<BF16> { static constexpr uint32_t v = 0x3f803f80u; };
 template <> struct Ones2<F16> { static constexpr uint32_t v = 0x3c003c00u; };
 
-// One logit through the reference's two roundings.
-template <typename T>
-__device__ __forceinline__ float logit_chain(float acc, const H2OParams& p) {
-  float x = Elem<T>::to_f32(Elem<T>::from_f32(acc));                       // matmul output dtype (:544)
-  x = scale_logit<T>(x, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);             // / math.sqrt(head_dim)
-  return Elem<T>::to_f32(Elem<T>::from_f32(x));
-}
-template <>
-__device__ __forceinline__ float logit_chain<BF16>(float acc, const H2OParams& p) {
-  float x = __uint_as_float(round_pack2<BF16>(0.f, acc));                  // matmul output dtype (:544); low half = +0
-  x = x * p.rcp_sqrt_d;                                                    // / math.sqrt(head_dim): exact for bf16, see scale_logit
-  return __uint_as_float(round_pack2<BF16>(0.f, x));
-}
-
 // ------------------------------------------------------------------------------------------------
 // Tiling shared by both passes.  A workgroup (4 waves) keeps 64 * NCT "resident" rows per wave in registers as MFMA
 // B operands (NCT column tiles of 32 rows x 2*KS k-steps x 16 B per lane) and streams the other matrix in 64-row
