@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PKV_VERSION 100 /* 0.1.0 */
+#define PKV_VERSION 101 /* 0.1.1: pkv_desc.tie_order */
 /* libpkv.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table (plus nothing). */
 #define PKV_API __attribute__((visibility("default")))
 
@@ -53,6 +53,12 @@ enum pkv_reduce { PKV_REDUCE_SUM = 0, PKV_REDUCE_MEAN = 1 };
 /* how A/sqrt(D) is evaluated (pyramidkv_utils.py:317): DIV = fp32 division (ATen CPU),
  * RCP = multiply by fp32 reciprocal (ATen GPU kernels for a host-scalar divisor). */
 enum pkv_scale { PKV_SCALE_DIV = 0, PKV_SCALE_RCP = 1 };
+/* Order of EQUAL scores in the selected rows (pyramidkv_utils.py:334: `tensor.topk` leaves it to the backend).
+ * CANONICAL = (value descending, index ascending) = a stable descending sort - what PyTorch-ROCm's topk produces for k > 32.
+ * ATEN_ROCM: for topk <= 32 additionally reproduce the order PyTorch-ROCm's topk leaves equal scores in (its k <= 32 results go
+ * through an unstable 32-element bitonic network, ATen/native/hip/SortUtils.cuh bitonicSortKVInPlace): the cache rows of
+ * PyramidKV's upper layers (k = 17..32) then sit in the order of a reference run on the same GPU.  Same token set either way. */
+enum pkv_tie { PKV_TIE_CANONICAL = 0, PKV_TIE_ATEN_ROCM = 1 };
 
 typedef struct pkv_desc {
   int32_t dtype;        /* pkv_dtype of q,k,v and of every score buffer */
@@ -68,6 +74,7 @@ typedef struct pkv_desc {
   int32_t reduce;       /* pkv_reduce: SUM for SnapKV/PyramidKV (:327), MEAN for AdaKV/HeadKV (:661) */
   int32_t scale_mode;   /* pkv_scale */
   int32_t topk;         /* k = past tokens kept per head, 1..S-window (host-resolved per layer) */
+  int32_t tie_order;    /* a pkv_tie value, honoured by the selecting entry points pkv_compress, pkv_compress_h2o, pkv_select on bf16 / fp16 scores; 0 = canonical */
 } pkv_desc;
 
 PKV_API int pkv_version(void);

@@ -18,6 +18,7 @@ PKV_BF16, PKV_F16, PKV_F32 = 0, 1, 2
 POOL = {None: 0, "none": 0, "avgpool": 1, "maxpool": 2}
 REDUCE = {"sum": 0, "mean": 1}
 SCALE = {"div": 0, "rcp": 1}
+TIE = {"canonical": 0, "aten_rocm": 1}
 KERNEL_NAMES = ["logits", "finalize", "topk", "gather", "h2o_stats", "h2o_colsum", "sort", "budget"]
 
 
@@ -27,7 +28,7 @@ class PkvDesc(C.Structure):
         ("kv_group", C.c_int32),
         ("q_stride", C.c_int64 * 3), ("k_stride", C.c_int64 * 3), ("v_stride", C.c_int64 * 3),
         ("window", C.c_int32), ("pool_kind", C.c_int32), ("pool_kernel", C.c_int32),
-        ("reduce", C.c_int32), ("scale_mode", C.c_int32), ("topk", C.c_int32),
+        ("reduce", C.c_int32), ("scale_mode", C.c_int32), ("topk", C.c_int32), ("tie_order", C.c_int32),
     ]
 
 

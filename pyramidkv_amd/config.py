@@ -14,3 +14,8 @@ gqa_dedup = os.environ.get("PKV_GQA_DEDUP", "0") == "1"
 # Ada-SnapKV needs its head capacities on the host (klen_sum / max_seqlen_k are Python ints at the boundary).  1 (default):
 # the budget kernel writes them into pinned host memory and the host polls a sequence word; 0: copy + stream synchronise.
 host_poll = os.environ.get("PKV_HOST_POLL", "1") == "1"
+
+# Order of equal scores in the selected rows: "canonical" = (value descending, index ascending), what PyTorch-ROCm's topk gives
+# for k > 32; "aten_rocm" additionally reproduces, for k <= 32, the order its unstable small-slice sort leaves them in - the
+# cache rows of PyramidKV's upper layers (k = 17..32) then match a reference run on the same GPU row for row.
+tie_order = os.environ.get("PKV_TIE_ORDER", "canonical")

@@ -102,6 +102,7 @@ int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true, bool f32_
   if (scoring && (d->window > 128 || d->kv_group * d->window > 256)) return PKV_ERR_UNSUPPORTED;
   if (need_topk && (d->topk < 1 || d->topk > d->S - d->window)) return PKV_ERR_SHAPE;
   if (d->pool_kind < 0 || d->pool_kind > 2) return PKV_ERR_SHAPE;
+  if (d->tie_order != PKV_TIE_CANONICAL && d->tie_order != PKV_TIE_ATEN_ROCM) return PKV_ERR_SHAPE;
   if (d->pool_kind != PKV_POOL_NONE) {
     if (d->pool_kernel < 1 || !(d->pool_kernel & 1)) return PKV_ERR_SHAPE;
     if (d->pool_kernel > 17) return PKV_ERR_UNSUPPORTED;
@@ -379,6 +380,10 @@ int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, c
                cm ? w + L.off_cmax : nullptr, L.Lp / 8,
                w + L.off_tk, L.tk_bytes);
   if (rc) return rc;
+  if (d->tie_order == PKV_TIE_ATEN_ROCM && d->dtype != PKV_F32) {             // k <= 32: the order PyTorch-ROCm's topk leaves ties in
+    hipError_t e = launch_aten_small_order(d->dtype, d->B * d->H, d->topk, scores, L.Lp, idx, d->topk, st);
+    if (e != hipSuccess) return hip_fail(e);
+  }
   GatherParams g = make_gather(d, k, v, k_out, v_out);
   g.idx = idx; g.idx_stride = d->topk;
   return do_gather(g, d->topk + d->window, st);
@@ -506,8 +511,14 @@ int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int
   const bool cm = !h2o && d->dtype != PKV_F32 && env_int("PKV_TOPK_CMAX", 1) != 0;
   rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
-  return do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx_out, d->topk, st,
-                 cm ? w + L.off_cmax : nullptr, L.Lp / 8, w + L.off_tk, L.tk_bytes);
+  rc = do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx_out, d->topk, st,
+               cm ? w + L.off_cmax : nullptr, L.Lp / 8, w + L.off_tk, L.tk_bytes);
+  if (rc) return rc;
+  if (d->tie_order == PKV_TIE_ATEN_ROCM && d->dtype != PKV_F32) {
+    hipError_t e = launch_aten_small_order(d->dtype, d->B * d->H, d->topk, scores, L.Lp, idx_out, d->topk, st);
+    if (e != hipSuccess) return hip_fail(e);
+  }
+  return PKV_OK;
 }
 
 namespace {

@@ -200,6 +200,9 @@ hipError_t launch_topk_merge_prep(int dtype, int rows, int L, int k, int nseg, i
                                   const int32_t* cand_idx, void* cand_score, int64_t cand_stride, hipStream_t st);
 hipError_t launch_topk_merge_finish(int rows, int k, const int32_t* cand_idx, int64_t cand_stride, const int32_t* pos, int32_t* idx_out,
                                     int64_t idx_stride, hipStream_t st);
+// PKV_TIE_ATEN_ROCM: rows of k <= 32 canonical indices -> the order PyTorch-ROCm's topk gives them (16-bit scores)
+hipError_t launch_aten_small_order(int dtype, int rows, int k, const void* scores, int64_t scores_stride, int32_t* idx, int64_t idx_stride,
+                                   hipStream_t st);
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);
 hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);

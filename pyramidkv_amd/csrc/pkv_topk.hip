@@ -874,4 +874,69 @@ hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// PKV_TIE_ATEN_ROCM (round 4): the order PyTorch-ROCm's tensor.topk leaves EQUAL scores in for k <= 32.
+// ATen gathers the winners in two passes - the scores above the k-th value in index order, then the ties of the k-th value
+// in index order - and sorts that list (value descending) with a 32-element bitonic network of compare-exchanges that also
+// move equal keys (ATen/native/hip/SortUtils.cuh: bitonicSort<32> / bitonicSwap; slices of 33..128 go through a stable warp
+// merge sort, longer ones through a stable radix sort: those ARE the canonical order).  One wave per row replays exactly
+// that on the canonical list topk_kernel wrote: rank every entry into the gather order, run the network, write the row back.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void aten_small_order_kernel(const uint16_t* scores, int64_t scores_stride, int32_t* idx, int64_t idx_stride, int k) {
+  __shared__ float key[32];
+  __shared__ int32_t val[32];
+  __shared__ bool ok[32];
+  const int row = blockIdx.x, lane = threadIdx.x;
+  int32_t* ir = idx + (int64_t)row * idx_stride;
+  const bool have = lane < k;
+  const int my = have ? ir[lane] : 0;
+  const float v = have ? Elem<T>::to_f32(scores[(int64_t)row * scores_stride + my]) : 0.f;
+  auto gt = [](float a, float b) { return (a != a && b == b) || a > b; };          // GTOp with NaN ranked largest
+  const float vk = __shfl(v, k - 1, 64);                                           // canonical order: entry k-1 holds the k-th value
+  const bool me_first = gt(v, vk);
+  int rank = 0;
+  for (int j = 0; j < k; ++j) {                                                     // wave-uniform trip count
+    const float vj = __shfl(v, j, 64);
+    const int ij = __shfl(my, j, 64);
+    const bool j_first = gt(vj, vk);
+    if (me_first) rank += (j_first && ij < my) ? 1 : 0;
+    else rank += (j_first || ij < my) ? 1 : 0;
+  }
+  if (lane < 32) { key[lane] = 0.f; val[lane] = 0; ok[lane] = false; }
+  __syncthreads();
+  if (have) { key[rank] = v; val[rank] = my; ok[rank] = true; }
+  const unsigned t = (unsigned)lane;                                                // 16 workers, two entries each
+  auto cswap = [&](unsigned a, unsigned b, bool dir) {
+    const bool swap = (gt(key[a], key[b]) && ok[a]) || !ok[b];                      // invalid entries sort to the end
+    if (swap == dir) {
+      const float kf = key[a]; key[a] = key[b]; key[b] = kf;
+      const int32_t vi = val[a]; val[a] = val[b]; val[b] = vi;
+      const bool vb = ok[a]; ok[a] = ok[b]; ok[b] = vb;
+    }
+  };
+  for (unsigned size = 2; size < 32; size *= 2) {
+    const bool flag = (t & (size / 2)) != 0;
+    for (unsigned stride = size / 2; stride > 0; stride /= 2) {
+      __syncthreads();
+      if (t < 16) { const unsigned pos = 2 * t - (t & (stride - 1)); cswap(pos, pos + stride, flag); }
+    }
+  }
+  for (unsigned stride = 16; stride > 0; stride /= 2) {
+    __syncthreads();
+    if (t < 16) { const unsigned pos = 2 * t - (t & (stride - 1)); cswap(pos, pos + stride, false); }
+  }
+  __syncthreads();
+  if (have) ir[lane] = val[lane];
+}
+
+hipError_t launch_aten_small_order(int dtype, int rows, int k, const void* scores, int64_t scores_stride, int32_t* idx, int64_t idx_stride, hipStream_t st) {
+  if (k < 2 || k > 32) return hipSuccess;                                           // k = 1: nothing to order; k > 32: ATen's sorts are stable
+  const uint16_t* sc = reinterpret_cast<const uint16_t*>(scores);
+  if (dtype == 0) hipLaunchKernelGGL(aten_small_order_kernel<BF16>, dim3(rows), dim3(64), 0, st, sc, scores_stride, idx, idx_stride, k);
+  else hipLaunchKernelGGL(aten_small_order_kernel<F16>, dim3(rows), dim3(64), 0, st, sc, scores_stride, idx, idx_stride, k);
+  return hipGetLastError();
+}
+
 }  // namespace pkv

@@ -11,6 +11,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _native as N
+from . import config as _cfg
 
 _WS: Dict[Tuple[int, int], torch.Tensor] = {}
 # Superseded workspaces stay alive while a HIP graph captured earlier may still have their address baked in.  Growth is
@@ -107,6 +108,7 @@ def make_desc(q: Optional[torch.Tensor], k: torch.Tensor, v: Optional[torch.Tens
     d.reduce = N.REDUCE[reduce]
     d.scale_mode = N.SCALE[scale_mode]
     d.topk = topk
+    d.tie_order = N.TIE[_cfg.tie_order]
     return d
 
 
@@ -117,7 +119,7 @@ def _scoring_desc(q, k, v, window, pooling, kernel_size, reduce, scale_mode, top
     """(descriptor, pkv_workspace_bytes(descriptor)) for a scoring call, cached by everything the descriptor is made of:
     filling the ctypes struct and asking the library for the scratch size are ~5 us of host time per call otherwise."""
     key = (k.dtype, q.shape, k.shape, q.stride(), k.stride(), v.stride() if v is not None else None, window, pooling, kernel_size,
-           reduce, scale_mode, topk, kv_group)
+           reduce, scale_mode, topk, kv_group, _cfg.tie_order)
     hit = _DESC_CACHE.get(key)
     if hit is None:
         if len(_DESC_CACHE) > 4096:

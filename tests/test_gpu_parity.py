@@ -491,6 +491,38 @@ def test_pyramid_layers_and_branches(P):
     assert kc is k3 and vc is v3
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_tie_order_aten_rocm_reproduces_torch_topk_rows_for_small_k(P, dt):
+    """config.tie_order = "aten_rocm" (round 4): for k <= 32 the selected rows come in the order PyTorch-ROCm's own
+    ``tensor.topk`` gives them on this GPU (pyramidkv_utils.py:334 - what a reference run here would put into the cache),
+    for k > 32 the canonical order already is that order.  Checked on the kernel's own pooled scores (maxpool-7: every local
+    maximum repeats seven times, so nearly every row is full of ties) and on rows of a few distinct values."""
+    import pyramidkv_amd.config as cfg
+    S, w = 8200, 8
+    q, k, v = make_qkv(2, 8, S, 128, dt, "gauss", 77)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    scores = P.ops.score_window(qd, kd, w, "maxpool", 7)
+    old = cfg.tie_order
+    try:
+        for kk in (2, 5, 17, 31, 32, 33, 64, 234):
+            want = scores.contiguous().topk(kk, dim=-1).indices
+            cfg.tie_order = "aten_rocm"
+            kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk, "maxpool", 7, return_indices=True)
+            sel = P.ops.select(qd, kd, w, kk, "maxpool", 7)
+            cfg.tie_order = "canonical"
+            _, _, idx_c = P.ops.compress(qd, kd, vd, w, kk, "maxpool", 7, return_indices=True)
+            assert torch.equal(idx.long(), want), kk                                  # row for row torch's order
+            assert torch.equal(sel, idx)
+            assert torch.equal(torch.sort(idx, -1).values, torch.sort(idx_c, -1).values)     # the same token set either way
+            kr, vr = O.gather_compact(k, v, idx.cpu().long(), w)
+            assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+            if kk > 32:
+                assert torch.equal(idx, idx_c)
+        _report(f"tie_order_aten_rocm/{dt}", dict(rows_identical_to_torch_rocm_topk=1.0, k=[2, 5, 17, 31, 32, 33, 64, 234]))
+    finally:
+        cfg.tie_order = old
+
+
 def test_cluster_index_out_receives_the_selected_indices(P):
     """``cluster.index_out`` (round 4; what bench.py and a head-sharded host use): update_kv also leaves its selected indices
     in the caller's int32 [B,H,k] tensor - the indices of the one-call path, K/V unchanged - for expanded and un-expanded K/V."""
