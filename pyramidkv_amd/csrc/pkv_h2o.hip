@@ -9,82 +9,54 @@
 //   h2o_knorm_kernel   per KV head: the largest squared key norm (64 partial maxima; a 45 us scan of K)
 //   h2o_stats_kernel   per query row: c_row = -log2 sum_j exp(x_ij)  (softmax denominator, log domain)
 //   h2o_colsum_kernel  per key column: sum over all query rows of round(exp2(x*log2e + c_row))
-// Both big passes recompute the logits with v_mfma_f32_32x32x16 and apply the reference's three roundings.
+// Both big passes recompute the logits with mfma_f32_16x16x32 and apply the reference's three roundings.
+// exp: every probability is ONE v_exp_f32 of fma(x, log2e, c_row) (the 1/Z factor folded into the exponent), relative
+// error ~|x*log2e| * 2^-24 (about 1e-6).  That is ~20x the error of the window path's exp, and deliberately so: a score
+// here is a sum over S >= 1000s of rounded probabilities, so the rare rounding flips (1e-6 / 2^-9 per element) average out
+// far below the model-dtype resolution of the sum (measured against the oracle in tests/test_gpu_parity.py::test_h2o_*),
+// while the kernels are instruction-issue-bound and the accurate exp costs 8 vector instructions per S x S element.
+// Probabilities below 2^-126 are +0 (the hardware exp2 and the MFMA operands flush them): scores below ~1e-35 come out 0.
 //
-// What bounds them (round 4 account with counters, clocks and power: profiles/r04/h2o_account.md).  A SIMD issues ONE vector
-// instruction per 4 cycles (wave64 on 16 lanes; v_exp_f32 takes two such slots), and while an MFMA executes the vector
-// port is blocked for ~60 % of its duration (4 + 6 of the 16 cycles of a 16x16x32, 4 + 15 of the 32 of a 32x32x16,
-// from the counters of three kernel generations): cycles ~ 4 x (vector instructions + exps) + 0.6 x matrix-pipe cycles,
-// whatever the order of the instructions.  On random data the chip additionally sits at its ~1300 W power cap and gives
-// cycle savings back as clock (2.29 -> 2.14 GHz between round 3's kernels and these; zero-filled inputs run at 2.39
-// GHz).  What this file does about the cycle count:
-//   * no running maximum in pass 1.  softmax needs SOME reference point M_i with exp(x - M_i) in fp32 range, not the
-//     maximum: M_i = |q_i| * max_j|k_j| / sqrt(D) * 1.02 - 64 is an upper bound of every logit of the row (Cauchy-
+// What bounds them (round 4 account with counters, clocks and power: profiles/r04/h2o/h2o_account.md).  A SIMD issues ONE
+// vector instruction per 4 cycles (wave64 on 16 lanes; v_exp_f32 takes two such slots), and while an MFMA executes the
+// vector port is blocked for part of its duration: cycles ~ 4 x (vector instructions + exps) + ~0.4 x matrix-pipe cycles,
+// whatever the order of the instructions.  On random data the chip additionally sits at its ~1300 W power cap and trades
+// cycles for clock - which is why THIS form ships and not round 4's 32x32x16 software pipeline (tools/probes/
+// h2o_wide_pipeline.hip: 14.5 % fewer cycles in pass 1, 7 % faster on zero-filled operands, but clocked 8 % lower on N(0,1)
+// data and 3 % SLOWER there than the kernels below; its accumulators move twice the register bytes per flop).
+// The levers that are in:
+//   * no running maximum in pass 1 (round 4).  softmax needs SOME reference point M_i with exp(x - M_i) in fp32 range, not
+//     the maximum: M_i = |q_i| * max_j|k_j| / sqrt(D) * 1.02 - 64 is an upper bound of every logit of the row (Cauchy-
 //     Schwarz on the rounded operands, 2 % for the two roundings) shifted so that a row maximum anywhere in
-//     [bound - 105, bound] keeps Z_i = sum exp(x - M_i) inside [2^-60, 2^112]: 6 vector instructions per element
-//     (round, scale, round, fma, exp2, add) instead of 6.75 + a wave-uniform branch per 4 elements.  A workgroup whose
-//     rows leave that window (Z < 2^-60, inf or NaN: key norms far above what the row actually attends to) repeats its
-//     rows with the exact online maximum - same kernel, second instance of the loop;
-//   * c_row = mL - log2 Z is independent of the reference point (= -log2 sum_j exp x_ij), so pass 2 does not care:
-//     every probability is ONE v_exp_f32 of fma(x, log2e, c_row), relative error ~1e-6.  A score is a sum over
-//     S >= 1000s of rounded probabilities, the rare rounding flips average out far below the model-dtype resolution
-//     (measured against the oracle in tests/test_gpu_parity.py::test_h2o_*).  Probabilities below 2^-126 are +0 (the
-//     hardware exp2 and the MFMA operands flush them): scores below ~1e-35 come out as 0;
-//   * 32x32x16 MFMAs (half the matrix instructions of round 3's 16x16x32) and an explicit software pipeline: the MFMAs
-//     of the NEXT 32-row sub-tile are issued between the slices (groups of four logits) of the current sub-tile's
-//     epilogue, pinned with sched_barrier - the compiler's own order is "all MFMAs, then 200 vector instructions";
+//     [bound - 105, bound] keeps Z_i = sum exp(x - M_i) inside [2^-60, 2^112]: 6 vector instructions per element (round,
+//     scale, round, fma, exp2, add) instead of 6.75 + a wave-uniform branch per 4 elements.  A workgroup whose rows leave
+//     that window (Z < 2^-60, inf or NaN: key norms far above what the row actually attends to) repeats its rows with
+//     the exact online maximum - same kernel, second instance of the loop.  c_row = mL - log2 Z does not depend on the
+//     reference point, so pass 2 does not care;
 //   * bf16 rounding as v_cvt_pk_bf16_f32 v, 0, x: the rounded value lands in the HIGH half over a zero low half, which
-//     IS its fp32 representation - 1 instruction per rounding;
-//   * no packed-fp32 arithmetic (v_pk_mul/add/fma_f32 cost several slots beside MFMAs): this file is compiled with
-//     -fno-slp-vectorize, the compiler otherwise packs the adds of the row sums;
-//   * pass 2 sums the columns ON THE MATRIX PIPE: P rounded to the model dtype is exact as an MFMA operand, and a
-//     16x16x32 MFMA with a 0/1 selector as A adds this lane's 8 query rows of two key columns into an fp32 accumulator;
+//     IS its fp32 representation - 1 instruction per rounding instead of pack + shift/mask (1.5);
+//   * no packed-fp32 arithmetic (v_pk_mul/fma_f32 cost several issue slots beside MFMAs): compiled with -fno-slp-vectorize;
+//   * pass 2 sums the columns ON THE MATRIX PIPE: P rounded to the model dtype is exact as an MFMA operand, so
+//     ones[16 x 32] x P[32 queries x 16 keys] adds 32 query rows per instruction into an fp32 accumulator (all 16 rows
+//     of the result hold the same sums) instead of unpack + add per element;
 //   * rows past S carry c_row = -inf (probability exactly 0) and tile loads are raw buffer loads whose addresses are
 //     advanced on the scalar unit and which return 0 past the end: no tail code, no per-tile vector address arithmetic;
 //   * pass 1 runs its end-of-row / masked-corner handling in a separate instance of the loop body.
-// Built, measured and removed in round 4 (h2o_account.md): the scale by 1/sqrt(D) on the matrix pipe (x*c_hi + x*c_lo
-// through a 16x16x32 MFMA whose A operand holds the two bf16 terms of c: one vector instruction per element less, exact
-// for every bf16 x - and 2 % SLOWER: the extra matrix time blocks the port as long as the multiply it replaces, and
-// costs power); tile loads that always read tile 0 (no memory stream at all) change nothing: the loop is not memory bound.
+// Pass 1: 6 vector instructions per element (2 roundings + scale 3, fma, exp2, add) + 1 MFMA, pass 2: 5.5 (3, fma, exp2,
+// pack 0.5) + 1.125 MFMA.  Built, measured and removed over three rounds (h2o_account.md, LABNOTES.md): rotated loops with
+// pinned MFMAs, 32x32x16 MFMAs with an explicit software pipeline, the scale by 1/sqrt(D) on the matrix pipe, forced
+// occupancy, tile loads without a memory stream (the loop is not memory bound).
 #include <type_traits>
 #include "pkv_common.hpp"
 #include "pkv_kernels.hpp"
 
-// compile-time shape knobs (A/B builds only; the defaults are the shipped configuration)
-#ifndef H2O_LB
-#define H2O_LB 2          // minimum waves per SIMD the register allocation aims at
-#endif
-#ifndef H2O_PIPE
-#define H2O_PIPE 1        // software pipeline (head sizes 64 and 128; 256 keeps the plain loop: its fragments fill the registers)
-#endif
-#ifndef H2O_TRACK
-#define H2O_TRACK 0       // 1: pass 1 always runs the exact online-maximum loop (measurement of what the bound saves)
-#endif
-#ifndef H2O_ABLATE
-#define H2O_ABLATE 0      // measurement only, WRONG results: 1 = every tile load reads tile 0 (no HBM / L2 stream behind the loop)
-#endif
-
 namespace pkv {
 
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
-typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8_t;
 
-// v_mfma_f32_32x32x16: A = 32 rows x 16 k (lane: row = lane & 31, 8 k-values of half lane >> 5), B = 16 k x 32 columns
-// (lane: column = lane & 31, same 8 k-values), D[row 8*(v/4) + 4*(lane>>5) + v%4][column lane & 31] in register v.
-template <typename T> struct MfmaW;
-template <> struct MfmaW<BF16> {
-  static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-  }
-};
-template <> struct MfmaW<F16> {
-  static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-  }
-};
-template <typename T> struct Mfma2;                   // 16x16x32 (the column sums of pass 2)
+template <typename T> struct Mfma2;
 template <> struct Mfma2<BF16> {
   static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -99,35 +71,53 @@ template <typename T> struct Ones2;                   // two 1.0 of the model dt
 template <> struct Ones2<BF16> { static constexpr uint32_t v = 0x3f803f80u; };
 template <> struct Ones2<F16> { static constexpr uint32_t v = 0x3c003c00u; };
 
+// v_max3_f32 on raw registers: fmaxf() of a value that came through integer bit operations makes the compiler
+// canonicalise it first (one extra v_max per operand)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// One logit through the reference's two roundings.
+template <typename T>
+__device__ __forceinline__ float logit_chain(float acc, const H2OParams& p) {
+  float x = Elem<T>::to_f32(Elem<T>::from_f32(acc));                       // matmul output dtype (:544)
+  x = scale_logit<T>(x, p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);             // / math.sqrt(head_dim)
+  return Elem<T>::to_f32(Elem<T>::from_f32(x));
+}
+template <>
+__device__ __forceinline__ float logit_chain<BF16>(float acc, const H2OParams& p) {
+  float x = __uint_as_float(round_pack2<BF16>(0.f, acc));                  // matmul output dtype (:544); low half = +0
+  x = x * p.rcp_sqrt_d;                                                    // / math.sqrt(head_dim): exact for bf16, see scale_logit
+  return __uint_as_float(round_pack2<BF16>(0.f, x));
+}
+template <typename T>
+__device__ __forceinline__ void logits4(const f32x4& acc, const H2OParams& p, float (&x)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) x[r] = logit_chain<T>(acc[r], p);
+}
+
 // ------------------------------------------------------------------------------------------------
-// Tiling shared by both passes.  A workgroup (4 waves) keeps 64 * NCT "resident" rows per wave in registers as MFMA
-// B operands (NCT column tiles of 32 rows x 2*KS k-steps x 16 B per lane) and streams the other matrix in 64-row
-// tiles through LDS, where all four waves read it (one L2 read per workgroup instead of one per wave: without this
-// the kernels are L2-bandwidth bound).  Staging is global -> VGPR -> ds_write, double buffered, the next tile's
-// global loads in flight while the current one is consumed.
-// LDS tile = [64 rows][CPR = 4*KS chunks of 16 B]; chunk c of row r is stored at chunk c ^ sw(r), so the A-fragment
-// read (lane (row = lane & 31, half = lane >> 5) reads chunk 2*kk + half) is bank-conflict free: the 16 lanes of one
-// ds_read_b128 group cover 16 different 16-byte bank groups.
+// Tiling shared by both passes.  A workgroup (4 waves) keeps 256 "resident" rows in registers as MFMA
+// B operands (64 per wave = 4 column tiles x 4 k-steps x 16 B per lane) and streams the other matrix
+// in 64-row tiles through LDS, where all four waves read it (one L2 read per workgroup instead of one
+// per wave: without this the kernels are L2-bandwidth bound).  Staging is global -> VGPR -> ds_write,
+// double buffered, the next tile's global loads in flight while the current one is consumed.
+// LDS tile = [64 rows][16 chunks of 16 B]; chunk c of row r is stored at chunk c ^ (r & 15), so the
+// A-fragment read (lane (li, lg) reads row li, chunk kk*4+lg) is bank-conflict free.
 // ------------------------------------------------------------------------------------------------
 constexpr int HT = 64;                 // streamed rows per LDS tile
-constexpr int NCH = 64;                // partial key-norm maxima per KV head
+constexpr int HR = 64;                 // resident rows per wave
+constexpr int HWG = 4 * HR;            // resident rows per workgroup
 
-// KS = head_dim / 32 (2, 4, 8 for head sizes 64, 128, 256).  A row is CPR = 4 * KS chunks of 16 B = 2 * KS k-steps.
-template <int KS> struct Shape {
-  static constexpr int CPR = 4 * KS;
-  static constexpr int NK = 2 * KS;                       // 32x32x16 k-steps per row
-  static constexpr int NCT = KS >= 8 ? 1 : 2;             // resident column tiles (32 rows each) per wave: register budget
-  static constexpr int HR = 32 * NCT;                     // resident rows per wave
-  static constexpr int HWG = 4 * HR;                      // resident rows per workgroup
-  static __device__ __forceinline__ int sw(int r) { return CPR == 8 ? ((r >> 1) & 7) : (r & 15); }
-};
-
+// KS = head_dim / 32 MFMA k-steps (2, 4, 8 for head sizes 64, 128, 256).  A row is CPR = 4 * KS chunks of 16 B.
 template <int KS> struct Stager {      // one thread's share of a 64-row tile: 64 * CPR / 256 = KS chunks of 16 B
   u32x4 v[KS];
 };
 
-// The streamed matrix of one head as a raw buffer.  Per thread one byte offset (row tid/CPR, chunk tid%CPR), computed
-// once; per tile the descriptor's base and extent move on the scalar unit; rows r0+RPP*i come through the scalar offset.
+// The streamed matrix of one head as a raw buffer.  Per thread one byte offset (row tid/16, chunk tid%16), computed
+// once; per tile the descriptor's base and extent move on the scalar unit; rows r0+16i come through the scalar offset.
 // A load that starts past `extent` returns 0, so the last tile needs no clamping.
 struct TileStream {
   const uint16_t* base;                // row 0 of the head
@@ -146,9 +136,6 @@ __device__ __forceinline__ TileStream make_stream(const uint16_t* base, int64_t 
 template <int KS>
 __device__ __forceinline__ void stage_load(Stager<KS>& st, const TileStream& s, int row0) {
   constexpr int CPR = 4 * KS, RPP = 256 / CPR;                             // rows covered by one pass of the 256 threads
-#if H2O_ABLATE == 1
-  row0 = 0;
-#endif
   const int left = s.nrows - row0;                                          // rows still inside the matrix (scalar)
   const int64_t ext = left > 0 ? (int64_t)(left - 1) * s.stride_b + CPR * 16 : 0;
   const uint32_t extent = ext > 0xffffffffll ? 0xffffffffu : (uint32_t)ext;
@@ -158,52 +145,44 @@ __device__ __forceinline__ void stage_load(Stager<KS>& st, const TileStream& s, 
   for (int i = 0; i < KS; ++i)
     st.v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, s.voff, (uint32_t)(RPP * i) * (uint32_t)s.stride_b, 0));
 }
+// chunk c of row r sits at chunk c ^ (r & SW): the fragment read below (16 rows x one chunk per 4-lane group) is then
+// bank-conflict free; SW = 15 for 16 and 32 chunks per row, 7 for 8
 template <int KS>
 __device__ __forceinline__ void stage_store(const Stager<KS>& st, u32x4* tile, int tid) {
-  constexpr int CPR = 4 * KS, RPP = 256 / CPR;
+  constexpr int CPR = 4 * KS, RPP = 256 / CPR, SW = CPR >= 16 ? 15 : CPR - 1;
   const int c = tid % CPR, r0 = tid / CPR;
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
     const int r = r0 + RPP * i;
-    tile[r * CPR + (c ^ Shape<KS>::sw(r))] = st.v[i];
+    tile[r * CPR + (c ^ (r & SW))] = st.v[i];
   }
 }
-// A fragments of the 32-row sub-tile `sub`: k-steps [k0, k0 + N)
-template <int KS, int N>
-__device__ __forceinline__ void read_frags(u32x4 (&f)[N], const u32x4* tile, int sub, int k0, int ln, int lh) {
-  constexpr int CPR = 4 * KS;
-  const int r = sub * 32 + ln;
-  const int s = Shape<KS>::sw(r);
+template <int KS>
+__device__ __forceinline__ void read_frags(u32x4 (&f)[KS], const u32x4* tile, int sub, int li, int lg) {
+  constexpr int CPR = 4 * KS, SW = CPR >= 16 ? 15 : CPR - 1;
+  const int r = sub * 16 + li;
 #pragma unroll
-  for (int kk = 0; kk < N; ++kk) f[kk] = tile[r * CPR + ((2 * (k0 + kk) + lh) ^ s)];
+  for (int kk = 0; kk < KS; ++kk) f[kk] = tile[r * CPR + ((kk * 4 + lg) ^ (li & SW))];
 }
 template <int KS>
-__device__ __forceinline__ void read_frag1(u32x4& f, const u32x4* tile, int sub, int kk, int ln, int lh) {
-  const int r = sub * 32 + ln;
-  f = tile[r * (4 * KS) + ((2 * kk + lh) ^ Shape<KS>::sw(r))];
-}
-// resident rows: B fragments straight from global memory (once per workgroup)
-template <int KS>
-__device__ __forceinline__ void load_frags(u32x4 (&f)[2 * KS], const uint16_t* base, int64_t row, int64_t stride, int lh) {
-  const uint16_t* r = base + row * stride + lh * 8;
+__device__ __forceinline__ void load_frags(u32x4 (&f)[KS], const uint16_t* base, int64_t row, int64_t stride, int lg) {
+  const uint16_t* r = base + row * stride + lg * 8;
 #pragma unroll
-  for (int kk = 0; kk < 2 * KS; ++kk) f[kk] = *reinterpret_cast<const u32x4*>(r + kk * 16);
+  for (int kk = 0; kk < KS; ++kk) f[kk] = *reinterpret_cast<const u32x4*>(r + kk * 32);
 }
-// the MFMAs of one 32-row sub-tile (fragments f = A) against the wave's resident rows (B): NCT independent accumulators.
-// D[streamed row][resident row].
+// the 16 MFMAs of one 16-row sub-tile (fragments f, the A operand) against the wave's 64 resident rows (B): four
+// independent accumulators back to back, no dependent-MFMA stall.  D[streamed row][resident row].
 template <typename T, int KS>
-__device__ __forceinline__ void mm32(f32x16 (&acc)[Shape<KS>::NCT], const u32x4 (&f)[2 * KS], const u32x4 (&res)[Shape<KS>::NCT][2 * KS]) {
-  constexpr int NCT = Shape<KS>::NCT;
+__device__ __forceinline__ void mm16(f32x4 (&acc)[4], const u32x4 (&f)[KS], const u32x4 (&res)[4][KS]) {
 #pragma unroll
-  for (int n = 0; n < NCT; ++n)
+  for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+  for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-  for (int kk = 0; kk < 2 * KS; ++kk)
-#pragma unroll
-    for (int n = 0; n < NCT; ++n) acc[n] = MfmaW<T>::run(f[kk], res[n][kk], acc[n]);
+    for (int n = 0; n < 4; ++n) acc[n] = Mfma2<T>::run(f[kk], res[n][kk], acc[n]);
 }
 
+constexpr int NCH = 64;                // partial key-norm maxima per KV head
 template <typename T> __device__ __forceinline__ float sumsq8(u32x4 v);
 template <> __device__ __forceinline__ float sumsq8<BF16>(u32x4 v) {
   float s = 0.f;
@@ -258,319 +237,178 @@ __global__ __launch_bounds__(256) void h2o_knorm_kernel(H2OParams p) {
   if (tid == 0) p.knorm[(int64_t)bhk * NCH + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
 
-// ---- the epilogue of four logits of one lane, in two stages ------------------------------------------------------
-// stage A: matmul-dtype rounding and the scale
-template <typename T>
-__device__ __forceinline__ void scale4(const f32x16& a, const int g, const H2OParams& p, float (&t)[4]) {
-  if constexpr (std::is_same<T, BF16>::value) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = __uint_as_float(round_pack2<BF16>(0.f, a[4 * g + r])) * p.rcp_sqrt_d;   // exact for bf16, see scale_logit
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = scale_logit<T>(Elem<T>::to_f32(Elem<T>::from_f32(a[4 * g + r])), p.scale_mode, p.sqrt_d, p.rcp_sqrt_d);
-  }
-}
-// stage B, first half: the second rounding -> the reference's logit
-template <typename T> __device__ __forceinline__ float round_logit(float t) { return Elem<T>::to_f32(Elem<T>::from_f32(t)); }
-template <> __device__ __forceinline__ float round_logit<BF16>(float t) { return __uint_as_float(round_pack2<BF16>(0.f, t)); }
-
-// Pass 1: per query row, c_row = -log2 sum_j exp(x_ij).  Resident = query rows, streamed = K.
-// Per-lane statistics (a lane's column = one query, 16 keys per 32-key sub-tile and column tile).
+// Pass 1: per query row, c_row = -log2 sum_j exp(x_ij).  Resident = 256 query rows, streamed = K.
+// Per-lane statistics (lane's column = one query, 4 keys per 16-key subtile).  Bound path: exponentials relative to the row's
+// norm bound, no maximum; exact path (rows outside the window): the running maximum is only rescaled when some lane of the
+// wave actually found a larger logit (wave-uniform branch).
 template <typename T, int KS>
-__global__ __launch_bounds__(256, H2O_LB) void h2o_stats_kernel(H2OParams p) {
-  using SH = Shape<KS>;
-  constexpr int NCT = SH::NCT, NK = SH::NK;
-  constexpr int NG = 4 * NCT;                                                            // 4-logit groups per lane and sub-tile
-  constexpr bool PIPE = H2O_PIPE && KS < 8;
-  constexpr int MPS = NK / 4;                                                            // main MFMAs per slice (NK * NCT / NG)
+__global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char h2o_smem[];               // 2 tiles (64 KB at head size 256)
   u32x4 (*tiles)[HT * 4 * KS] = reinterpret_cast<u32x4 (*)[HT * 4 * KS]>(h2o_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ln = lane & 31, lh = lane >> 5;
+  const int li = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y;
   const int b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
   const int S = p.S, L = S - p.w;
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b + (int64_t)h * p.qs_h;
   const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
-  const int q0 = blockIdx.x * SH::HWG + wave * SH::HR;
-  u32x4 qf[NCT][NK];
-  int qi[NCT];
+  const int q0 = blockIdx.x * HWG + wave * HR;
+  u32x4 qf[4][KS];
+  int qi[4];
 #pragma unroll
-  for (int n = 0; n < NCT; ++n) {
-    qi[n] = q0 + n * 32 + ln;
-    load_frags<KS>(qf[n], qb, qi[n] < S ? qi[n] : S - 1, p.qs_s, lh);
+  for (int n = 0; n < 4; ++n) {
+    qi[n] = q0 + n * 16 + li;
+    load_frags<KS>(qf[n], qb, qi[n] < S ? qi[n] : S - 1, p.qs_s, lg);
   }
   const float L2E = 1.44269504088896340736f;
-  // reference point of the row's exponentials: upper bound of every logit, shifted down by 64 (see the header)
+  float m[4], mL[4], Z[4];          // running max, -max*log2e, running sum of exp
+  // reference point of the bound path: upper bound of every logit of the row, shifted down by 64
   const float kmax2 = wave_max(p.knorm[((int64_t)b * (p.H / p.G) + hk) * NCH + lane]);
-  float mL0[NCT];
-  bool wild = false;                      // norms that are not finite: no bound, straight to the exact loop
+  float mL0[4];
+  bool wild = false;
 #pragma unroll
-  for (int n = 0; n < NCT; ++n) {
+  for (int n = 0; n < 4; ++n) {
     float s = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) s += sumsq8<T>(qf[n][kk]);
+    for (int kk = 0; kk < KS; ++kk) s += sumsq8<T>(qf[n][kk]);
+    s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    const float ub = __builtin_sqrtf(s * kmax2) * 1.02f;                    // bound of |q.k|
+    const float ub = __builtin_sqrtf(s * kmax2) * 1.02f;
     wild |= !(ub < INFINITY);
     mL0[n] = (64.0f - ub * p.rcp_sqrt_d) * L2E;
   }
 
   const TileStream ks = make_stream<KS>(kb, p.ks_s, S, tid);
+  Stager<KS> stg;
+  stage_load<KS>(stg, ks, 0);
+  stage_store<KS>(stg, tiles[0], tid);
+  __syncthreads();
   const int ntiles = (S + HT - 1) / HT;
-  const int t_plain = (L < S ? L : S) / HT;                                   // tiles [0, t_plain) end at or before L
-  float m[NCT], mL[NCT], Z[NCT];          // running max (exact loop only), -reference*log2e, running sum of exp
-
-  // whole epilogue of one 32-key sub-tile that starts at key s0 (edge tiles, the exact loop, H2O_PIPE = 0)
-  auto epilogue = [&](const f32x16 (&acc)[NCT], const int s0, auto edge_tag, auto track_tag) __attribute__((always_inline)) {
+  // tiles that touch the end of the row or the masked corner run the EDGE instance of the body; all others carry no
+  // masking code at all
+  auto tile_body = [&](const int t, auto edge_tag, auto track_tag) {
     constexpr bool edge = decltype(edge_tag)::value, track = decltype(track_tag)::value;
+    const int s_tile = t * HT;
+    const u32x4* cur = tiles[t & 1];
+    stage_load<KS>(stg, ks, s_tile + HT);                                     // in flight during the compute below; past the end: zeros
 #pragma unroll
-    for (int n = 0; n < NCT; ++n) {
-      float x[16];
+    for (int sub = 0; sub < 4; ++sub) {
+      u32x4 kf[KS];
+      read_frags<KS>(kf, cur, sub, li, lg);
+      const int s0 = s_tile + sub * 16;
+      f32x4 accs[4];
+      mm16<T, KS>(accs, kf, qf);                                              // D[key][query]
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float t4[4];
-        scale4<T>(acc[n], g, p, t4);
+      for (int n = 0; n < 4; ++n) {
+        float x[4];
+        logits4<T>(accs[n], p, x);
+        if (edge) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[4 * g + r] = round_logit<T>(t4[r]);
-      }
-      if (edge) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int s = s0 + 8 * (e >> 2) + 4 * lh + (e & 3);
-          // corner mask (:545-551): the reference adds finfo.min, whose exp(x - max) is exactly 0 next to any visible
-          // key (every row sees at least one) - so is exp(-inf), and -inf keeps a lane that has seen ONLY masked keys
-          // out of the statistics (its maximum would be -3.4e38 for bf16, and -max * log2e overflows)
-          if (qi[n] >= L && s >= L && (s - L) > (qi[n] - L)) x[e] = -INFINITY;
-          if (s >= S) x[e] = -INFINITY;
+          for (int r = 0; r < 4; ++r) {
+            const int s = s0 + lg * 4 + r;
+            // corner mask (:545-551): the reference adds finfo.min, whose exp(x - max) is exactly 0 next to any visible
+            // key (every row sees at least one) - so is exp(-inf), and -inf keeps a lane that has seen ONLY masked keys
+            // out of the statistics (its maximum would be -3.4e38 for bf16, and -max * log2e overflows)
+            if (qi[n] >= L && s >= L && (s - L) > (qi[n] - L)) x[r] = -INFINITY;
+            if (s >= S) x[r] = -INFINITY;
+          }
         }
-      }
-      if (track) {
-        float mx = m[n];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, x[e]);
-        if (__any(mx > m[n])) {                                               // rare once the maxima settle
-          Z[n] = (m[n] == -INFINITY) ? 0.f : Z[n] * __builtin_amdgcn_exp2f((m[n] - mx) * L2E);
-          m[n] = mx;
-          mL[n] = (mx == -INFINITY) ? 0.f : -mx * L2E;
+        const float mx = track ? max3_raw(max3_raw(x[0], x[1], x[2]), x[3], m[n]) : 0.f;
+        if (track && __any(mx > m[n])) {                                      // rare once the maxima settle
+          const float mn = fmaxf(m[n], mx);
+          Z[n] = (m[n] == -INFINITY) ? 0.f : Z[n] * __builtin_amdgcn_exp2f((m[n] - mn) * L2E);
+          m[n] = mn;
+          mL[n] = (mn == -INFINITY) ? 0.f : -mn * L2E;
         }
-      }
-      float zs[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
         float y[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(x[4 * g + r], L2E, mL[n]);
-        zs[g] = (__builtin_amdgcn_exp2f(y[0]) + __builtin_amdgcn_exp2f(y[1])) +
+        for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(x[r], L2E, mL[n]);
+        Z[n] += (__builtin_amdgcn_exp2f(y[0]) + __builtin_amdgcn_exp2f(y[1])) +
                 (__builtin_amdgcn_exp2f(y[2]) + __builtin_amdgcn_exp2f(y[3]));
       }
-      Z[n] += (zs[0] + zs[1]) + (zs[2] + zs[3]);
     }
-  };
-
-  // One step of the software pipeline (plain tiles of the bound path): the MFMAs of the NEXT sub-tile (fragments of
-  // tile[sub] -> nxt) are issued between the slices of the CURRENT sub-tile's epilogue (cur).  A slice = one group of
-  // four logits: stage A (round, scale: two packs + one small MFMA) of group i and stage B (round, fma, exp2, add) of
-  // group i - 1, whose scaled values `pend` were produced one slice - or, for i = 0, one sub-tile - earlier, around
-  // NK / 4 main MFMAs.  sched_barrier(0) between slices: left to itself the scheduler emits the main MFMAs back to back
-  // and ~200 vector instructions behind them; each wave then alternates between a phase that only needs the matrix pipe
-  // and one that only needs the vector port, and two waves per SIMD cover each other badly (35 % of the wave cycles
-  // were issue stalls, the vector port 66 % busy; profiles/r04/h2o_account.md).
-  float pend[4];
-  auto step = [&](const f32x16 (&cur)[NCT], f32x16 (&nxt)[NCT], const u32x4* tile, const int sub) __attribute__((always_inline)) {
-    // fragment kk is read one slice before the slice whose MFMAs use it (two slices' worth in flight at the start)
-    u32x4 kf[NK];
-    constexpr int K0 = (2 * MPS - 1) / NCT < NK - 1 ? (2 * MPS - 1) / NCT : NK - 1;
-#pragma unroll
-    for (int kk = 0; kk <= K0; ++kk) read_frag1<KS>(kf[kk], tile, sub, kk, ln, lh);
-#pragma unroll
-    for (int n = 0; n < NCT; ++n)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) nxt[n][e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      constexpr int H1 = (MPS + 1) / 2;
-      const int np = i == 0 ? NCT - 1 : (i - 1) / 4;                          // column tile of the pending group
-      if (i >= 1 && i + 1 < NG) {
-#pragma unroll
-        for (int kk = ((i + 1) * MPS - 1) / NCT + 1; kk <= ((i + 2) * MPS - 1) / NCT; ++kk) read_frag1<KS>(kf[kk], tile, sub, kk, ln, lh);
-      }
-#pragma unroll
-      for (int j = 0; j < H1; ++j) {
-        const int idx = i * MPS + j, kk = idx / NCT, n = idx % NCT;
-        nxt[n] = MfmaW<T>::run(kf[kk], qf[n][kk], nxt[n]);
-      }
-      float tn[4];
-      scale4<T>(cur[i / 4], i % 4, p, tn);
-      float y[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(round_logit<T>(pend[r]), L2E, mL[np]);
-#pragma unroll
-      for (int j = H1; j < MPS; ++j) {
-        const int idx = i * MPS + j, kk = idx / NCT, n = idx % NCT;
-        nxt[n] = MfmaW<T>::run(kf[kk], qf[n][kk], nxt[n]);
-      }
-      Z[np] += (__builtin_amdgcn_exp2f(y[0]) + __builtin_amdgcn_exp2f(y[1])) + (__builtin_amdgcn_exp2f(y[2]) + __builtin_amdgcn_exp2f(y[3]));
-      // stage B has no consumer before the end of the loop: without this anchor instruction selection sinks all of them
-      // behind the last slice (sched_barrier only orders what carries a side effect)
-      asm volatile("" : "+v"(Z[np]));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pend[r] = tn[r];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  auto run_pass = [&](auto track_tag) __attribute__((always_inline)) {
-    constexpr bool track = decltype(track_tag)::value;
-    Stager<KS> stg;
-    stage_load<KS>(stg, ks, 0);
-    stage_store<KS>(stg, tiles[0], tid);
+    stage_store<KS>(stg, tiles[(t + 1) & 1], tid);                            // buffer last read in iteration t-1
     __syncthreads();
-    int t = 0;
-    if constexpr (PIPE) {
-      // rotated: the MFMAs of the next sub-tile are in flight while the current sub-tile's epilogue issues
-      f32x16 accA[NCT], accB[NCT];
-      {
-        u32x4 kf[NK];
-        read_frags<KS, NK>(kf, tiles[0], 0, 0, ln, lh);
-        mm32<T, KS>(accA, kf, qf);
-      }
-      // cur = t & 1 is a literal in the two-tile main loop: every LDS address is then a constant offset
-      auto tile_fast = [&](const int t, const int cur) __attribute__((always_inline)) {
-        stage_load<KS>(stg, ks, t * HT + HT);                                 // in flight during the compute below; past the end: zeros
-        step(accA, accB, tiles[cur], 1);
-        stage_store<KS>(stg, tiles[cur ^ 1], tid);                            // buffer last read in iteration t-1
-        __syncthreads();
-        step(accB, accA, tiles[cur ^ 1], 0);                                  // tile t+1 (zeros past the end)
-      };
-      if (!track) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pend[r] = -INFINITY;                      // exp2(-inf) = 0: nothing pending yet
-        for (; t + 2 <= t_plain; t += 2) { tile_fast(t, 0); tile_fast(t + 1, 1); }
-        for (; t < t_plain; ++t) tile_fast(t, t & 1);
-        float y[4];                                                           // the last group of the last plain sub-tile
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = __builtin_fmaf(round_logit<T>(pend[r]), L2E, mL[NCT - 1]);
-        Z[NCT - 1] += (__builtin_amdgcn_exp2f(y[0]) + __builtin_amdgcn_exp2f(y[1])) + (__builtin_amdgcn_exp2f(y[2]) + __builtin_amdgcn_exp2f(y[3]));
-      }
-      // tiles that touch the end of the row or the masked corner (and every tile of the exact loop): the whole epilogue
-      // of a sub-tile behind the MFMAs of the next one, masking code only in the EDGE instance
-      auto tile_body = [&](const int t, const int cur, auto edge_tag) __attribute__((always_inline)) {
-        const int s_tile = t * HT;
-        stage_load<KS>(stg, ks, s_tile + HT);
-        {
-          u32x4 kf[NK];
-          read_frags<KS, NK>(kf, tiles[cur], 1, 0, ln, lh);
-          mm32<T, KS>(accB, kf, qf);
-        }
-        epilogue(accA, s_tile, edge_tag, track_tag);
-        stage_store<KS>(stg, tiles[cur ^ 1], tid);
-        __syncthreads();
-        {
-          u32x4 kf[NK];
-          read_frags<KS, NK>(kf, tiles[cur ^ 1], 0, 0, ln, lh);
-          mm32<T, KS>(accA, kf, qf);
-        }
-        epilogue(accB, s_tile + 32, edge_tag, track_tag);
-      };
-      for (; t < t_plain; ++t) tile_body(t, t & 1, std::false_type{});
-      for (; t < ntiles; ++t) tile_body(t, t & 1, std::true_type{});
-    } else {
-      auto tile_body = [&](const int t, const int cur, auto edge_tag) __attribute__((always_inline)) {
-        const int s_tile = t * HT;
-        stage_load<KS>(stg, ks, s_tile + HT);
-#pragma unroll
-        for (int sub = 0; sub < HT / 32; ++sub) {
-          u32x4 kf[NK];
-          read_frags<KS, NK>(kf, tiles[cur], sub, 0, ln, lh);
-          f32x16 acc[NCT];
-          mm32<T, KS>(acc, kf, qf);
-          epilogue(acc, s_tile + sub * 32, edge_tag, track_tag);
-        }
-        stage_store<KS>(stg, tiles[cur ^ 1], tid);
-        __syncthreads();
-      };
-      for (; t < t_plain; ++t) tile_body(t, t & 1, std::false_type{});
-      for (; t < ntiles; ++t) tile_body(t, t & 1, std::true_type{});
-    }
   };
-
+  const int t_plain = (L < S ? L : S) / HT;                                   // tiles [0, t_plain) end at or before L
   float* rs = p.rowstat + (int64_t)bh * S;
-#if !H2O_TRACK
   if (!__syncthreads_or(wild)) {
 #pragma unroll
-    for (int n = 0; n < NCT; ++n) { m[n] = 0.f; mL[n] = mL0[n]; Z[n] = 0.f; }
-    run_pass(std::false_type{});
+    for (int n = 0; n < 4; ++n) { m[n] = 0.f; mL[n] = mL0[n]; Z[n] = 0.f; }
+    for (int t = 0; t < t_plain; ++t) tile_body(t, std::false_type{}, std::false_type{});
+    for (int t = t_plain; t < ntiles; ++t) tile_body(t, std::true_type{}, std::false_type{});
     bool bad = false;
-    float zt[NCT];
+    float zt[4];
 #pragma unroll
-    for (int n = 0; n < NCT; ++n) {
-      zt[n] = Z[n] + __shfl_xor(Z[n], 32, 64);
-      bad |= !(zt[n] >= 0x1p-60f && zt[n] <= 0x1p120f);                     // outside the window, inf or NaN
+    for (int n = 0; n < 4; ++n) {
+      zt[n] = Z[n] + __shfl_xor(Z[n], 16, 64);
+      zt[n] += __shfl_xor(zt[n], 32, 64);
+      bad |= !(zt[n] >= 0x1p-60f && zt[n] <= 0x1p120f);
     }
     if (!__syncthreads_or(bad)) {
 #pragma unroll
-      for (int n = 0; n < NCT; ++n) {
-        // c_row = mL - log2 Z with Z = 2^e * f: (mL - e) and log2 f are both small numbers
+      for (int n = 0; n < 4; ++n) {
         const int e = __builtin_amdgcn_frexp_expf(zt[n]);
         const float f = __builtin_amdgcn_frexp_mantf(zt[n]);
-        if (lh == 0 && qi[n] < S) rs[qi[n]] = (mL[n] - (float)e) - __builtin_amdgcn_logf(f);
+        if (lg == 0 && qi[n] < S) rs[qi[n]] = (mL[n] - (float)e) - __builtin_amdgcn_logf(f);
       }
       return;
     }
+    // repeat with the exact online maximum: restage tile 0
+    stage_load<KS>(stg, ks, 0);
+    stage_store<KS>(stg, tiles[0], tid);
+    __syncthreads();
   }
-#endif
-  // exact online maximum: every row of the workgroup once more (or always, H2O_TRACK)
 #pragma unroll
-  for (int n = 0; n < NCT; ++n) { m[n] = -INFINITY; mL[n] = 0.f; Z[n] = 0.f; }
-  run_pass(std::true_type{});
+  for (int n = 0; n < 4; ++n) { m[n] = -INFINITY; mL[n] = 0.f; Z[n] = 0.f; }
+  for (int t = 0; t < t_plain; ++t) tile_body(t, std::false_type{}, std::true_type{});
+  for (int t = t_plain; t < ntiles; ++t) tile_body(t, std::true_type{}, std::true_type{});
 #pragma unroll
-  for (int n = 0; n < NCT; ++n) {
+  for (int n = 0; n < 4; ++n) {
     float mm = m[n], zz = Z[n];
-    const float mo = __shfl_xor(mm, 32, 64), zo = __shfl_xor(zz, 32, 64);
-    const float mn = fmaxf(mm, mo);
-    const float za = (mm == -INFINITY) ? 0.f : zz * __builtin_amdgcn_exp2f((mm - mn) * L2E);
-    const float zb = (mo == -INFINITY) ? 0.f : zo * __builtin_amdgcn_exp2f((mo - mn) * L2E);
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float mo = __shfl_xor(mm, o, 64), zo = __shfl_xor(zz, o, 64);
+      const float mn = fmaxf(mm, mo);
+      const float za = (mm == -INFINITY) ? 0.f : zz * __builtin_amdgcn_exp2f((mm - mn) * L2E);
+      const float zb = (mo == -INFINITY) ? 0.f : zo * __builtin_amdgcn_exp2f((mo - mn) * L2E);
+      mm = mn; zz = za + zb;
+    }
     // c_row = -(m*log2e + log2 Z): pass 2 evaluates exp(x - m) / Z as exp2(x*log2e + c_row)
-    if (lh == 0 && qi[n] < S) rs[qi[n]] = -(mn * L2E + __builtin_amdgcn_logf(za + zb));
+    if (lg == 0 && qi[n] < S) rs[qi[n]] = -(mm * L2E + __builtin_amdgcn_logf(zz));
   }
 }
 
-// Pass 2: per key column, sum over all query rows of round(exp2(x*log2e + c_row)).  Resident = key columns,
+// Pass 2: per key column, sum over all query rows of round(exp(x - m) / Z).  Resident = 256 key columns,
 // streamed = Q (+ the 64 row constants c_row of the tile).  No branch in the loop.
 template <typename T, int KS>
-__global__ __launch_bounds__(256, H2O_LB) void h2o_colsum_kernel(H2OParams p) {
-  using SH = Shape<KS>;
-  constexpr int NCT = SH::NCT, NK = SH::NK;
-  constexpr int NG = 4 * NCT, MPS = NK / 4;
-  constexpr bool PIPE = H2O_PIPE && KS < 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char h2o_smem[];               // 2 tiles + 3 x 64 row constants
+__global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char h2o_smem[];               // 2 tiles + 2 x 64 row constants
   u32x4 (*tiles)[HT * 4 * KS] = reinterpret_cast<u32x4 (*)[HT * 4 * KS]>(h2o_smem);
   float (*stats)[HT] = reinterpret_cast<float (*)[HT]>(h2o_smem + (size_t)2 * HT * 4 * KS * 16);   // c_row of the 64 streamed query rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ln = lane & 31, lh = lane >> 5;
+  const int li = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y;
   const int b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
   const int S = p.S, L = S - p.w;
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.qs_b + (int64_t)h * p.qs_h;
   const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
   const float* rs = p.rowstat + (int64_t)bh * S;
-  const int k0 = blockIdx.x * SH::HWG + wave * SH::HR;
+  const int k0 = blockIdx.x * HWG + wave * HR;
 
-  u32x4 kf[NCT][NK];
+  u32x4 kf[4][KS];
+  int kj[4];
 #pragma unroll
-  for (int n = 0; n < NCT; ++n) {
-    const int kj = k0 + n * 32 + ln;
-    load_frags<KS>(kf[n], kb, kj < S ? kj : S - 1, p.ks_s, lh);
+  for (int n = 0; n < 4; ++n) {
+    kj[n] = k0 + n * 16 + li;
+    load_frags<KS>(kf[n], kb, kj[n] < S ? kj[n] : S - 1, p.ks_s, lg);
   }
-  // matrix-pipe column sums: B = this lane's 8 rounded probabilities (8 query rows of key column lane & 31), A = a 0/1
-  // selector: output row 0 adds the lane groups that hold columns 0-15 (lanes 0-15 and 32-47), output row 1 those with
-  // columns 16-31.  cacc[n][0] / [1] of lanes 0-15 = sums of columns lane / lane + 16 of column tile n.
-  f32x4 cacc[NCT];
+  // matrix-pipe column sums (see the header): every row of cacc[n] holds the sums of key columns kj[n]
+  f32x4 cacc[4];
 #pragma unroll
-  for (int n = 0; n < NCT; ++n) cacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint32_t sv = ((lane & 15) == ((lane >> 4) & 1)) ? Ones2<T>::v : 0u;
-  const u32x4 sel = {sv, sv, sv, sv};
+  for (int n = 0; n < 4; ++n) cacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = {Ones2<T>::v, Ones2<T>::v, Ones2<T>::v, Ones2<T>::v};
+  uint32_t held[4][2];
   const float L2E2 = 1.44269504088896340736f;
   auto row_const = [&](int i) {                                // rows past S: exp2(x*log2e - inf) = 0 (clamped load + select: no branch)
     const float c = rs[i < S ? i : S - 1];
@@ -578,173 +416,71 @@ __global__ __launch_bounds__(256, H2O_LB) void h2o_colsum_kernel(H2OParams p) {
   };
 
   const TileStream qs = make_stream<KS>(qb, p.qs_s, S, tid);
+  Stager<KS> stg;
+  stage_load<KS>(stg, qs, 0);
+  float sreg = row_const(lane);                                // all four waves carry the same 64 constants: no divergent branch
+  stage_store<KS>(stg, tiles[0], tid);
+  stats[0][lane] = sreg;
+  __syncthreads();
   const int ntiles = (S + HT - 1) / HT;
-
-  // whole epilogue of one 32-query sub-tile with row constants st (H2O_PIPE = 0)
-  auto epilogue = [&](const f32x16 (&acc)[NCT], const f32x4 (&st)[4]) __attribute__((always_inline)) {
+  for (int t = 0; t < ntiles; ++t) {
+    const u32x4* cur = tiles[t & 1];
+    const float* cst = stats[t & 1];
+    stage_load<KS>(stg, qs, (t + 1) * HT);                     // past the end: zeros (and c_row = -inf)
+    sreg = row_const((t + 1) * HT + lane);
 #pragma unroll
-    for (int n = 0; n < NCT; ++n) {
-      uint32_t pk[8];
+    for (int sub = 0; sub < 4; ++sub) {
+      u32x4 qf[KS];
+      read_frags<KS>(qf, cur, sub, li, lg);
+      const f32x4 st = *reinterpret_cast<const f32x4*>(cst + sub * 16 + lg * 4);
+      f32x4 accs[4];
+      mm16<T, KS>(accs, qf, kf);                               // D[query][key]
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float t4[4], e[4];
-        scale4<T>(acc[n], g, p, t4);
+      for (int n = 0; n < 4; ++n) {
+        float x[4], e[4];
+        logits4<T>(accs[n], p, x);                             // keys < L never touch the masked corner
 #pragma unroll
-        for (int r = 0; r < 4; ++r)                            // fp32 softmax (:553): exp(x - m) / Z; keys < L never touch the masked corner
-          e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(round_logit<T>(t4[r]), L2E2, st[g][r]));
-        pk[2 * g] = round_pack2<T>(e[0], e[1]);                // .to(dtype)
-        pk[2 * g + 1] = round_pack2<T>(e[2], e[3]);
-      }
-      cacc[n] = Mfma2<T>::run(sel, u32x4{pk[0], pk[1], pk[2], pk[3]}, cacc[n]);     // fp32 sum (:554)
-      cacc[n] = Mfma2<T>::run(sel, u32x4{pk[4], pk[5], pk[6], pk[7]}, cacc[n]);
-    }
-  };
-  // One step of the software pipeline (see h2o_stats_kernel): main MFMAs of the next sub-tile between the slices of the
-  // current one's epilogue.  Stage B of a group = round, fma with the row constants, exp2, pack; every second group
-  // completes the 8 probabilities of a column-sum MFMA.  Carried over the sub-tile boundary: the scaled values of the
-  // last group (pend), its row constants (pst) and the packed probabilities of the group before it (hold).
-  float pend[4];
-  f32x4 pst;
-  uint32_t hold[2];
-  auto step = [&](const f32x16 (&cur)[NCT], f32x16 (&nxt)[NCT], const u32x4* tile, const int sub, const float* cst) __attribute__((always_inline)) {
-    // fragment kk is read one slice before the slice whose MFMAs use it (two slices' worth in flight at the start)
-    u32x4 qf[NK];
-    constexpr int K0 = (2 * MPS - 1) / NCT < NK - 1 ? (2 * MPS - 1) / NCT : NK - 1;
-#pragma unroll
-    for (int kk = 0; kk <= K0; ++kk) read_frag1<KS>(qf[kk], tile, sub, kk, ln, lh);
-#pragma unroll
-    for (int n = 0; n < NCT; ++n)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) nxt[n][e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      constexpr int H1 = (MPS + 1) / 2;
-      const int gp = i == 0 ? NG - 1 : i - 1;                                 // the pending group: column tile gp / 4, row block gp % 4
-      const f32x4 cn = *reinterpret_cast<const f32x4*>(cst + 8 * (i % 4) + 4 * lh);   // row constants of group i: used one slice later
-      if (i >= 1 && i + 1 < NG) {
-#pragma unroll
-        for (int kk = ((i + 1) * MPS - 1) / NCT + 1; kk <= ((i + 2) * MPS - 1) / NCT; ++kk) read_frag1<KS>(qf[kk], tile, sub, kk, ln, lh);
-      }
-#pragma unroll
-      for (int j = 0; j < H1; ++j) {
-        const int idx = i * MPS + j, kk = idx / NCT, n = idx % NCT;
-        nxt[n] = MfmaW<T>::run(qf[kk], kf[n][kk], nxt[n]);
-      }
-      float tn[4];
-      scale4<T>(cur[i / 4], i % 4, p, tn);
-      float e[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(round_logit<T>(pend[r]), L2E2, pst[r]));
-#pragma unroll
-      for (int j = H1; j < MPS; ++j) {
-        const int idx = i * MPS + j, kk = idx / NCT, n = idx % NCT;
-        nxt[n] = MfmaW<T>::run(qf[kk], kf[n][kk], nxt[n]);
-      }
-      uint32_t p01 = round_pack2<T>(e[0], e[1]), p23 = round_pack2<T>(e[2], e[3]);         // .to(dtype)
-      asm volatile("" : "+v"(p01), "+v"(p23));                 // anchor of stage B in this slice (see h2o_stats_kernel)
-      if (gp & 1) cacc[gp / 4] = Mfma2<T>::run(sel, u32x4{hold[0], hold[1], p01, p23}, cacc[gp / 4]);   // fp32 sum (:554)
-      else { hold[0] = p01; hold[1] = p23; }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pend[r] = tn[r];
-      pst = cn;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  {
-    Stager<KS> stg;
-    stage_load<KS>(stg, qs, 0);
-    float sreg = row_const(lane);                              // all four waves carry the same 64 constants: no divergent branch
-    stage_store<KS>(stg, tiles[0], tid);
-    stats[0][lane] = sreg;
-    __syncthreads();
-    int t = 0;
-    if constexpr (PIPE) {
-      f32x16 accA[NCT], accB[NCT];
-      {
-        u32x4 qf[NK];
-        read_frags<KS, NK>(qf, tiles[0], 0, 0, ln, lh);
-        mm32<T, KS>(accA, qf, kf);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pend[r] = 0.f;               // nothing pending yet: probability exp2(0 - inf) = 0 ...
-      pst = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      hold[0] = hold[1] = 0u;                                  // ... and +0 from the group before it
-      // the row constants are triple buffered: tile t reads stats[t % 3] on BOTH sides of its barrier, tile t + 1's are written
-      // before it into the buffer tile t - 2 used
-      auto tile_body = [&](const int t, const int cur) __attribute__((always_inline)) {
-        stage_load<KS>(stg, qs, (t + 1) * HT);                 // past the end: zeros (and c_row = -inf)
-        sreg = row_const((t + 1) * HT + lane);
-        const float* cst = stats[t % 3];
-        step(accA, accB, tiles[cur], 1, cst);                  // D[query][key]
-        stage_store<KS>(stg, tiles[cur ^ 1], tid);
-        stats[(t + 1) % 3][lane] = sreg;
-        __syncthreads();
-        step(accB, accA, tiles[cur ^ 1], 0, cst + 32);
-      };
-      for (; t + 2 <= ntiles; t += 2) { tile_body(t, 0); tile_body(t + 1, 1); }
-      for (; t < ntiles; ++t) tile_body(t, t & 1);
-      float e[4];                                              // the last group of the last sub-tile
-#pragma unroll
-      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(round_logit<T>(pend[r]), L2E2, pst[r]));
-      cacc[NCT - 1] = Mfma2<T>::run(sel, u32x4{hold[0], hold[1], round_pack2<T>(e[0], e[1]), round_pack2<T>(e[2], e[3])}, cacc[NCT - 1]);
-    } else {
-      for (; t < ntiles; ++t) {
-        const int cur = t & 1;
-        stage_load<KS>(stg, qs, (t + 1) * HT);
-        sreg = row_const((t + 1) * HT + lane);
-#pragma unroll
-        for (int sub = 0; sub < HT / 32; ++sub) {
-          u32x4 qf[NK];
-          read_frags<KS, NK>(qf, tiles[cur], sub, 0, ln, lh);
-          f32x16 acc[NCT];
-          mm32<T, KS>(acc, qf, kf);
-          f32x4 st[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) st[g] = *reinterpret_cast<const f32x4*>(stats[cur] + sub * 32 + 8 * g + 4 * lh);
-          epilogue(acc, st);
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r], L2E2, st[r]));   // fp32 softmax (:553): exp(x - m) / Z
+        const uint32_t p01 = round_pack2<T>(e[0], e[1]), p23 = round_pack2<T>(e[2], e[3]);              // .to(dtype)
+        if ((sub & 1) == 0) {
+          held[n][0] = p01; held[n][1] = p23;
+        } else {                                               // this lane's 8 query rows of key column li; fp32 sum (:554)
+          const u32x4 pb = {held[n][0], held[n][1], p01, p23};
+          cacc[n] = Mfma2<T>::run(ones, pb, cacc[n]);
         }
-        stage_store<KS>(stg, tiles[cur ^ 1], tid);
-        stats[cur ^ 1][lane] = sreg;
-        __syncthreads();
       }
     }
+    stage_store<KS>(stg, tiles[(t + 1) & 1], tid);
+    stats[(t + 1) & 1][lane] = sreg;
+    __syncthreads();
   }
-
   uint16_t* out = reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride;
-  if (lane < 16) {
 #pragma unroll
-    for (int n = 0; n < NCT; ++n) {
-      const int j0 = k0 + n * 32 + lane;
-      if (j0 < L) out[j0] = Elem<T>::from_f32(cacc[n][0]);
-      if (j0 + 16 < L) out[j0 + 16] = Elem<T>::from_f32(cacc[n][1]);
-    }
-  }
+  for (int n = 0; n < 4; ++n)                                  // the MFMA already summed the four lane groups
+    if (lg == 0 && kj[n] < L) out[kj[n]] = Elem<T>::from_f32(cacc[n][0]);
 }
+
 
 // raw-buffer tile loads carry 32-bit offsets: 64 rows of the streamed matrix must span less than 4 GB
 static bool strides_ok(const H2OParams& p) {
   return p.qs_s > 0 && p.ks_s > 0 && p.qs_s * 2 * 64 < (int64_t)0xffffffffll && p.ks_s * 2 * 64 < (int64_t)0xffffffffll;
 }
 
-#define PKV_H2O_DISPATCH(MACRO)                                                                                        \
-  if (dtype == 0) { if (p.D == 64) MACRO(BF16, 2); else if (p.D == 256) MACRO(BF16, 8); else MACRO(BF16, 4); }          \
-  else { if (p.D == 64) MACRO(F16, 2); else if (p.D == 256) MACRO(F16, 8); else MACRO(F16, 4); }
-
 hipError_t launch_h2o_knorm(int dtype, const H2OParams& p, hipStream_t st) {
   if (!strides_ok(p)) return hipErrorInvalidValue;
   dim3 grid(NCH, p.B * (p.H / p.G));
 #define PKV_H2O_N(TT, KS) hipLaunchKernelGGL((h2o_knorm_kernel<TT, KS>), grid, dim3(256), 0, st, p)
-  PKV_H2O_DISPATCH(PKV_H2O_N)
+  if (dtype == 0) { if (p.D == 64) PKV_H2O_N(BF16, 2); else if (p.D == 256) PKV_H2O_N(BF16, 8); else PKV_H2O_N(BF16, 4); }
+  else { if (p.D == 64) PKV_H2O_N(F16, 2); else if (p.D == 256) PKV_H2O_N(F16, 8); else PKV_H2O_N(F16, 4); }
 #undef PKV_H2O_N
   return hipGetLastError();
 }
 
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
   if (!strides_ok(p)) return hipErrorInvalidValue;
+  dim3 grid((p.S + HWG - 1) / HWG, p.B * p.H);
 #define PKV_H2O_S(TT, KS)                                                                                             \
   do {                                                                                                                \
-    dim3 grid((p.S + Shape<KS>::HWG - 1) / Shape<KS>::HWG, p.B * p.H);                                                \
     const size_t lds_ = (size_t)2 * HT * 4 * KS * 16;                                                                 \
     if (lds_ >= 64 * 1024) {                                                                                          \
       hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(h2o_stats_kernel<TT, KS>),                    \
@@ -753,7 +489,8 @@ hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
     }                                                                                                                 \
     hipLaunchKernelGGL((h2o_stats_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                     \
   } while (0)
-  PKV_H2O_DISPATCH(PKV_H2O_S)
+  if (dtype == 0) { if (p.D == 64) PKV_H2O_S(BF16, 2); else if (p.D == 256) PKV_H2O_S(BF16, 8); else PKV_H2O_S(BF16, 4); }
+  else { if (p.D == 64) PKV_H2O_S(F16, 2); else if (p.D == 256) PKV_H2O_S(F16, 8); else PKV_H2O_S(F16, 4); }
 #undef PKV_H2O_S
   return hipGetLastError();
 }
@@ -761,10 +498,10 @@ hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
 hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st) {
   if (!strides_ok(p)) return hipErrorInvalidValue;
   const int L = p.S - p.w;
+  dim3 grid((L + HWG - 1) / HWG, p.B * p.H);
 #define PKV_H2O_C(TT, KS)                                                                                             \
   do {                                                                                                                \
-    dim3 grid((L + Shape<KS>::HWG - 1) / Shape<KS>::HWG, p.B * p.H);                                                  \
-    const size_t lds_ = (size_t)2 * HT * 4 * KS * 16 + 3 * HT * 4;                                                    \
+    const size_t lds_ = (size_t)2 * HT * 4 * KS * 16 + 2 * HT * 4;                                                    \
     if (lds_ >= 64 * 1024) {                                                                                          \
       hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(h2o_colsum_kernel<TT, KS>),                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                    \
@@ -772,7 +509,8 @@ hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st) {
     }                                                                                                                 \
     hipLaunchKernelGGL((h2o_colsum_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                    \
   } while (0)
-  PKV_H2O_DISPATCH(PKV_H2O_C)
+  if (dtype == 0) { if (p.D == 64) PKV_H2O_C(BF16, 2); else if (p.D == 256) PKV_H2O_C(BF16, 8); else PKV_H2O_C(BF16, 4); }
+  else { if (p.D == 64) PKV_H2O_C(F16, 2); else if (p.D == 256) PKV_H2O_C(F16, 8); else PKV_H2O_C(F16, 4); }
 #undef PKV_H2O_C
   return hipGetLastError();
 }
