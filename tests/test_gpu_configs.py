@@ -135,7 +135,11 @@ def test_config3_h2o_32k_vs_oracle(P, dt):
                                 kv_identical=float(kv_h.float().mean()))
         # a score is a sum over 32768 rows; where the kernels' score differs from the oracle's by one unit (<= 1e-3 of them)
         # two neighbours of the ranking may swap, and at budget 2048 the last place may change hands
-        assert float(set_h.float().mean()) >= (1.0 if cap == 128 else 0.75), (cap, set_h)
+        # measured: the oracle's token SET in every head except one fp16 head at budget 2048 (its order in 8 / 8 heads at budget 128,
+        # 6 / 8 (bf16) and 1 / 8 (fp16) at budget 2048: fp16 H2O scores of 32k rows sit in a band a few units wide)
+        assert float(set_h.float().mean()) >= (1.0 if (cap == 128 or dt == "bf16") else 0.875), (cap, set_h)
+        if cap == 128:
+            assert bool(seq_h.all()), seq_h
         assert bool((kv_h | ~seq_h).all()), "same index sequence but different K/V bits"
     _report(f"config3/h2o/S32768/B2H4/{dt}", rep)
 
