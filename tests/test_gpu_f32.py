@@ -146,7 +146,8 @@ def test_merge_f32_vs_oracle(P, D, G, S):
     frac = float((close_k & close_v).float().mean())
     # a kept row differs only when a dropped row's two best similarities tie within fp32 noise and it chose the other one:
     # on N(0,1) keys that is a handful of the ~1e3 dropped rows at most, each moving at most two kept rows
-    assert frac >= 0.9, frac
+    # measured: every kept row of the three cases matches (a tie within fp32 noise would move at most two of them)
+    assert frac >= 1.0 - 4.0 / close_k.numel(), frac
     cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool", merge="pivot")
     k2, v2 = cl.update_kv(k_un.to(DEV), q.to(DEV), v_un.to(DEV), None, G)
     assert torch.equal(k2.cpu(), km) and torch.equal(v2.cpu(), vm)          # the cluster runs the same two calls
