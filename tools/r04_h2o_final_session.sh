@@ -10,7 +10,7 @@ timeout 2400 python -m pytest tests -m gpu -q --timeout 1500 > $O/pytest.txt 2>&
 echo "pytest exit $?" >> $O/pytest.txt
 grep -E "passed|failed|^FAILED|^ERROR|pytest exit" $O/pytest.txt | tail -8
 cp gpurun_out/parity_report.json $O/parity_report.json 2>/dev/null
-timeout 600 python tools/h2o_power.py tools/_h2o_base.so pyramidkv_amd/libpkv.so > $O/h2o_power.txt 2>&1
+timeout 600 python tools/h2o_power.py tools/_h2o_base.so tools/_h2o_wide.so pyramidkv_amd/libpkv.so > $O/h2o_power.txt 2>&1   # r03 / 32x32x16 pipeline (tools/build_h2o_variants.sh --src tools/probes/h2o_wide_pipeline.hip wide="") / shipped
 grep -v amdgpu.ids $O/h2o_power.txt
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_h2o -- python $R/tools/h2o_only.py 32768 > $O/prof_h2o.log 2>&1
