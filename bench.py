@@ -390,6 +390,7 @@ def main():
         out["extras"], gqa_rows = gqa_extra(P, N, rl, dt, dev, S, H, ks, a.steps)
         out["roofline_kernels"].update(gqa_rows)
         out["extras"]["two_streams"] = two_stream_extra(P, dt, dev, S, H, ks, a.steps)
+        out["extras"]["h2o"] = h2o_extra(P, N, dt, dev, S, H)
         out["sweep"] = seq_batch_sweep(P, dt, dev, H, alg_bytes)
         out["gpu_eager_baseline"] = gpu_eager_baseline(dt, dev, S, H, cap)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -564,6 +565,32 @@ def gqa_extra(P, N, rl, dt, dev, S, H, ks, steps):
             "call_effective_frac_of_8TBps": round(alg_total / (ge / steps / NUM_LAYERS) / 1e9 / HBM_PEAK_GBS, 4),
             "note": "K/V handed over before repeat_kv (8 KV heads for 32 query heads); not the headline value"}, \
         {k_: v_ for k_, v_ in rows.items() if v_}
+
+
+def h2o_extra(P, N, dt, dev, S, H):
+    """Extra (not `value`): BASELINE config 3's other policy - the H2O score of all S query rows (pyramidkv_utils.py:544-554),
+    the one kernel pair of this path that is bound by the matrix + vector pipes instead of HBM: 2 * 2 * S^2 * D * H flop against
+    the dense bf16 MFMA peak (2.5 PFLOP/s).  Device time of the two passes from events on the dispatches."""
+    (q, k, _), = make_sets(1, H, S, dt, dev, 808, 1)
+    for _ in range(2):
+        P.ops.score_h2o(q, k, W)
+    torch.cuda.synchronize()
+    N.prof_enable(True)
+    N.prof_read(reset=True)
+    iters = 5
+    for _ in range(iters):
+        P.ops.score_h2o(q, k, W)
+    torch.cuda.synchronize()
+    prof = N.prof_read(reset=True)
+    N.prof_enable(False)
+    ms = {kk: prof[kk][0] / max(1, prof[kk][1]) for kk in ("h2o_stats", "h2o_colsum")}
+    total = ms["h2o_stats"] + ms["h2o_colsum"]
+    flop = 2.0 * 2.0 * S * S * D * H
+    return {"h2o_score_ms": round(total, 3), "stats_ms": round(ms["h2o_stats"], 3), "colsum_ms": round(ms["h2o_colsum"], 3),
+            "roofline": {"bound": "mfma", "achieved": round(flop / (total * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flop / (total * 1e-3) / 1e12 / 2500.0, 4)},
+            "note": "[1,%d,%d,128] %s, N(0,1) inputs: the chip runs this pair at its power cap (profiles/r04/h2o/h2o_account.md)"
+                    % (H, S, str(dt).replace("torch.", ""))}
 
 
 def two_stream_extra(P, dt, dev, S, H, ks, steps):
