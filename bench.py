@@ -382,12 +382,16 @@ def main():
 
     if world == 1 and a.only_gqa_extra:
         out["extras"], gqa_rows = gqa_extra(P, N, rl, dt, dev, S, H, ks, a.steps)
+        if S == 32768 and a.budget == 128:
+            attach_north_traffic(gqa_rows)       # logits_gqa4: K read once per KV head + the logits write (PMC passes of this leg)
         out["roofline_kernels"].update(gqa_rows)
     elif world == 1 and not a.no_extras:
         out["grid"], north = grid_rows(P, N, dt, dev, S, H, rl, alg_bytes, kernel_rows)
         attach_north_traffic(north)
         out["roofline_kernels"].update(north)
         out["extras"], gqa_rows = gqa_extra(P, N, rl, dt, dev, S, H, ks, a.steps)
+        if S == 32768 and a.budget == 128:
+            attach_north_traffic(gqa_rows)
         out["roofline_kernels"].update(gqa_rows)
         out["extras"]["two_streams"] = two_stream_extra(P, dt, dev, S, H, ks, a.steps)
         out["extras"]["h2o"] = h2o_extra(P, N, dt, dev, S, H)

@@ -17,9 +17,18 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         if "pkv::" not in name:
             continue
         short = name.split("pkv::")[1].split("_kernel")[0]
+        pass_dir = os.path.basename(os.path.dirname(os.path.dirname(f)))
+        two_tiles = short == "logits2" and (", 2, " in name or ",2," in name)      # logits2_kernel<T, 2, NT>: 17..32 columns
         if short == "logits2":      # the pipelined variant of the logits kernel reports under the same profiler id
             short = "logits"
-        if os.path.basename(os.path.dirname(os.path.dirname(f))).startswith("pmc_gather"):
+        if pass_dir.startswith("pmc_gqa"):
+            # bench.py --only-gqa-extra: the headline kernels run as well; only the un-expanded-K scan (two column tiles) is new
+            if not two_tiles:
+                continue
+            short = "logits_gqa4"
+        elif two_tiles:
+            continue
+        if pass_dir.startswith("pmc_gather"):
             # tools/gather_pmc.py: budget-2048 gather, B = 1 (512 workgroups of 256 threads) and B = 8 (4096)
             if short != "gather":
                 continue

@@ -14,7 +14,7 @@ fi
 cp gpurun_out/parity_report.json $O/parity_report.json 2>/dev/null
 ./tools/bw_probe > $O/bw_probe.json 2> $O/bw_probe.err
 # HBM traffic counters first: the bench line attaches them when they belong to the current kernel sources
-(cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-parity > $O/pmc_fetch.log 2>&1 ; timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-parity > $O/pmc_write.log 2>&1 ; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_gather_fetch -- python $R/tools/gather_pmc.py > $O/pmc_gather_fetch.log 2>&1 ; timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_gather_write -- python $R/tools/gather_pmc.py > $O/pmc_gather_write.log 2>&1 ; python $R/tools/pmc_summary.py $O $O/pmc_traffic.json > $O/pmc_summary.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-parity > $O/pmc_fetch.log 2>&1 ; timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-parity > $O/pmc_write.log 2>&1 ; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_gather_fetch -- python $R/tools/gather_pmc.py > $O/pmc_gather_fetch.log 2>&1 ; timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_gather_write -- python $R/tools/gather_pmc.py > $O/pmc_gather_write.log 2>&1 ; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_gqa_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --only-gqa-extra --no-parity > $O/pmc_gqa_fetch.log 2>&1 ; timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_gqa_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --only-gqa-extra --no-parity > $O/pmc_gqa_write.log 2>&1 ; python $R/tools/pmc_summary.py $O $O/pmc_traffic.json > $O/pmc_summary.log 2>&1)
 mkdir -p $R/profiles/r04; cp $O/pmc_traffic.json $R/profiles/r04/pmc_traffic.json 2>/dev/null
 # issue-port counters of the four headline kernels (what DESIGN.md's "vector-issue-bound" statements rest on)
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_issue -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-parity > $O/pmc_issue.log 2>&1 ; timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/pmc_issue2 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-parity > $O/pmc_issue2.log 2>&1)
