@@ -1,7 +1,7 @@
 """Is the H2O pass limited by the chip's power budget?  For every library (PKV_LIB) and input kind, run the H2O score
 at S = 32768, H = 32 in a loop for ~2.5 s while rocm-smi samples power and shader clock, and report per-pass times
 (hipEvent, attached to the dispatches), mean power and mean sclk.
-  python tools/h2o_power.py lib [lib ...]"""
+  python tools/h2o_power.py lib [lib ...]        (env: H2O_S = sequence length, H2O_KINDS = randn,zeros,ones, H2O_SECONDS = 2.5)"""
 import json, os, re, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     import torch
     import pyramidkv_amd as P
     from pyramidkv_amd import _native as N
-    S = 32768
+    S = int(os.environ.get("H2O_S", "32768"))
     g = torch.Generator(device="cuda").manual_seed(5)
     qr, kr = (torch.randn(1, 32, S, 128, device="cuda", generator=g).to(torch.bfloat16) for _ in range(2))
     samples = []
@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
             except Exception as e:       # noqa: BLE001
                 samples.append((None, None))
             time.sleep(0.05)
-    for kind in ("randn", "zeros", "ones"):
+    for kind in os.environ.get("H2O_KINDS", "randn,zeros,ones").split(","):
         if kind == "randn":
             q, k = qr, kr
         elif kind == "zeros":
@@ -42,7 +42,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         th = threading.Thread(target=sampler); th.start()
         N.prof_enable(True); N.prof_read(True)
         t0 = time.time(); n = 0
-        while time.time() - t0 < 2.5:
+        while time.time() - t0 < float(os.environ.get("H2O_SECONDS", "2.5")):
             for _ in range(10):
                 P.ops.score_h2o(q, k, 8)
             torch.cuda.synchronize(); n += 10
@@ -52,7 +52,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         ms = {kk: round(v[0] / max(1, v[1]), 3) for kk, v in r.items() if kk.startswith("h2o") and v[1]}
         pw = [s[0] for s in samples[2:] if s[0]]
         sc = [s[1] for s in samples[2:] if s[1]]
-        print(json.dumps({"data": kind, "ms": ms, "wall_ms_per_call": round(1e3 * wall, 2), "calls": n,
+        print(json.dumps({"S": S, "data": kind, "ms": ms, "wall_ms_per_call": round(1e3 * wall, 2), "calls": n,
                           "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": max(pw) if pw else None,
                           "sclk_mhz_mean": round(sum(sc) / len(sc)) if sc else None, "samples": len(samples)}), flush=True)
     sys.exit(0)
