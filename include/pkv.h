@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PKV_VERSION 101 /* 0.1.1: pkv_desc.tie_order */
+#define PKV_VERSION 102 /* 0.1.2: pkv_ada_select accepts short candidate lists (with a host mirror); 0.1.1: pkv_desc.tie_order */
 /* libpkv.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table (plus nothing). */
 #define PKV_API __attribute__((visibility("default")))
 
@@ -200,6 +200,11 @@ PKV_API int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t 
 /* Fused front half of AdaKVCluster.update_kv / HeadKVCluster.update_kv (:674-731 / :808-852) in ONE call: window score
  * (d->reduce = PKV_REDUCE_MEAN, :661) -> top-M indices of every head (d->topk = M, canonical order) -> head budgets +
  * var-len metadata.  Ada-SnapKV: given_capacity = NULL, M >= min(S-w, H*base); writes head_capacity, head_lens, cu_klen.
+ * Short lists (0.1.2): with a host_mirror, base <= M < min(S-w, H*base) is accepted as well.  The budgets are then exact
+ * unless some head's list runs out at the global threshold; the kernel reports that in bit 30 of the mirror's sequence word
+ * (word H = host_seq | 0x40000000; host_seq itself must stay below 2^30) and the caller repeats the call with the full M.
+ * (A head of a real prompt takes a few base budgets, not H of them: 8 x base entries per head instead of H x base cut the
+ * selection from 21 to 16 us at S = 32768, H = 32, base = 120.)
  * HeadKV: given_capacity = device int32 [H] (host-derived, :855), M >= max capacity; writes head_lens, cu_klen only.
  * The host then reads the capacities back (klen_sum / max_seqlen_k are Python ints at the boundary, :685-686; the
  * reference has the same sync at :718) and calls pkv_gather_flat(top_idx, idx_stride = M, ...).  ws: pkv_workspace_bytes(d). */

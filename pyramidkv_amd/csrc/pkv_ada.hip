@@ -234,8 +234,13 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
       __hip_atomic_store(p.host_mirror + tid, cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __threadfence_system();
     }
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(p.host_mirror + p.H, p.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // Short lists (fewer than min(L, H*base) entries per head): the threshold and every count are exact as long as no list
+    // is used up at the threshold (counts above it are below the list length, so nothing was cut off).  A head whose whole
+    // list lies at or above the threshold may own more entries than the list shows: reported in bit 30 of the sequence
+    // word, and the caller repeats the call with the full length.
+    const int exhausted = __syncthreads_or(p.short_list && tid < p.H && gt + eq >= p.L);
+    if (tid == 0)
+      __hip_atomic_store(p.host_mirror + p.H, p.host_seq | (exhausted ? 0x40000000 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (head_lens && cu_klen) {                     // :684, :689-691: head_lens = cap + w, cu_klen = exclusive prefix + total
     __syncthreads();

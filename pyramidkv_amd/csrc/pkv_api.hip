@@ -600,7 +600,7 @@ int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, 
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);     // int(base_capacity * floor_ratio) (:632)
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr; bp.unsorted = 0;
   bp.window = 0; bp.head_lens_out = nullptr; bp.cu_klen_out = nullptr; bp.cu_headlens_out = nullptr;
-  bp.host_mirror = nullptr; bp.host_seq = 0; bp.adaptive_out = nullptr;
+  bp.host_mirror = nullptr; bp.host_seq = 0; bp.short_list = 0; bp.adaptive_out = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(dtype, bp, st);
@@ -627,7 +627,7 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr; bp.unsorted = 0;
   bp.window = window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = nullptr;
-  bp.host_mirror = nullptr; bp.host_seq = 0; bp.adaptive_out = nullptr;
+  bp.host_mirror = nullptr; bp.host_seq = 0; bp.short_list = 0; bp.adaptive_out = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(dtype, bp, st);
@@ -651,7 +651,7 @@ int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores,
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr; bp.unsorted = 1;
   bp.window = window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
-  bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.adaptive_out = nullptr;
+  bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.short_list = 0; bp.adaptive_out = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = dtype == PKV_F32 ? launch_budget_f32(bp, st) : launch_budget(dtype, bp, st);
@@ -673,7 +673,7 @@ int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t M, const
   bp.one_minus_floor = 1.0f; bp.floor_capacity = 0;
   bp.normalize = normalize; bp.head_capacity = nullptr; bp.ws = ws; bp.list_ws = nullptr; bp.unsorted = 0;
   bp.window = 0; bp.head_lens_out = nullptr; bp.cu_klen_out = nullptr; bp.cu_headlens_out = nullptr;
-  bp.host_mirror = nullptr; bp.host_seq = 0; bp.adaptive_out = lists_out;
+  bp.host_mirror = nullptr; bp.host_seq = 0; bp.short_list = 0; bp.adaptive_out = lists_out;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(dtype, bp, st);
@@ -693,7 +693,9 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   const int L = d->S - d->window, M = d->topk, H = d->H;
   if (!given_capacity) {
     if (H > 256 || base_capacity < 1 || base_capacity > L) return PKV_ERR_SHAPE;
-    if (M < std::min<int64_t>(L, (int64_t)H * base_capacity)) return PKV_ERR_SHAPE;
+    // M >= min(L, H*base) decides everything (pkv_ada_budget_topm).  A SHORTER list (>= base) is accepted together with a host
+    // mirror: the result is exact unless bit 30 of the mirror's sequence word says that some head's list ran out
+    if (M < std::min<int64_t>(L, (int64_t)H * base_capacity) && (!host_mirror || M < base_capacity || (host_seq & 0x40000000))) return PKV_ERR_SHAPE;
     if (M > 65536) return PKV_ERR_UNSUPPORTED;
   }
   WsLayout W = ws_layout(d);
@@ -719,6 +721,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = w + W.off_ada; bp.list_ws = w + W.off_ada_list; bp.unsorted = 0;
   bp.window = d->window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
   bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.adaptive_out = nullptr;
+  bp.short_list = M < std::min<int64_t>(L, (int64_t)H * base_capacity) ? 1 : 0;
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = launch_budget(d->dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);

@@ -139,6 +139,7 @@ struct BudgetParams {
   void* adaptive_out;        // optional: dtype [H][L] - emit every head's adaptive list (:711) and stop (head-sharded exchange)
   int32_t* host_mirror;      // optional: device-visible PINNED HOST memory [H+1]; gets the capacities, then host_seq in [H]
   int32_t host_seq;
+  int short_list;            // the lists are SHORTER than min(L, H*base): bit 30 of the sequence word reports a head whose list ran out
   int unsorted;              // 1: `scores` are the un-sorted rows [H][scores_stride] of length Lrow and no list is given
   void* list_ws;             // optional: H * roundup(L,8) * 2 bytes, 16-B aligned - the looked-up lists travel through it
   void* ws;                  // 1024 B ratios + 2 * H*256 int32

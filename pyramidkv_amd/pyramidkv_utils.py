@@ -305,18 +305,20 @@ class _HostMirror:
         return self.seq
 
     def wait(self, device):
+        """-> the H capacities; ``self.exhausted`` = bit 30 of the sequence word (short lists: some head's list ran out)."""
         a, H, seq = self.np, self.H, self.seq
         t_end = time.perf_counter() + 0.5
         spins = 0
-        while a[H] != seq:
+        while (a[H] & 0x3fffffff) != seq:
             spins += 1
             if spins & 63 == 0:
                 time.sleep(0)                    # hand the GIL to other host threads while the kernel runs
                 if time.perf_counter() > t_end:  # a lost signal must not hang the host: fall back
                     torch.cuda.current_stream(device).synchronize()
-                    if a[H] != seq:
+                    if (a[H] & 0x3fffffff) != seq:
                         raise RuntimeError("pyramidkv_amd: the budget kernel did not report its head capacities")
                     break
+        self.exhausted = bool(a[H] & 0x40000000)
         return a[:H].tolist()                    # copied out before the next call of this instance can reuse the buffer
 
 
@@ -437,14 +439,27 @@ class AdaKVCluster(_FlatPolicy):
                 mirror = getattr(self, "_mirror", None)
                 if mirror is None or mirror.H != num_heads:
                     mirror = self._mirror = _HostMirror(num_heads)
-            sorted_idx, cap, head_lens, cu, cuh = ops.ada_select(
-                query_states, key_states, self.window_size, self.pooling, self.kernel_size, M, self.base_capacity,
-                self.floor_ratio, bool(self.normalize), scale_mode=_cfg.scale_mode,
-                kv_group=_unexpanded_group(key_states, query_states),               # :647-672, :706-719, :682-691
-                host_mirror=mirror.t if mirror is not None else None, host_seq=mirror.next_seq() if mirror is not None else 0)
+            # Round 4: the lists start SHORT (config.ada_short_lists x base per head instead of M: the selection of 3840 entries
+            # per head is a third of this call at S = 32k, and no head of a real prompt comes near H x its base budget).  The
+            # budgets are exact unless the kernel reports a head whose list ran out (the threshold sits below the list's
+            # last entry); then the call is repeated with the full M.  The cluster - one per layer, :1049 - remembers twice the
+            # largest share it has seen.
+            m_use = M
+            if mirror is not None and _cfg.ada_short_lists > 0:
+                m_use = min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity))
             bound = num_heads * self.base_capacity + num_heads + num_heads * self.window_size
-            return self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, meta=(head_lens, cu, cuh),
-                                            rows_bound=bound, mirror=mirror)
+            while True:
+                sorted_idx, cap, head_lens, cu, cuh = ops.ada_select(
+                    query_states, key_states, self.window_size, self.pooling, self.kernel_size, m_use, self.base_capacity,
+                    self.floor_ratio, bool(self.normalize), scale_mode=_cfg.scale_mode,
+                    kv_group=_unexpanded_group(key_states, query_states),               # :647-672, :706-719, :682-691
+                    host_mirror=mirror.t if mirror is not None else None, host_seq=mirror.next_seq() if mirror is not None else 0)
+                out = self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, meta=(head_lens, cu, cuh),
+                                               rows_bound=bound, mirror=mirror)
+                if m_use == M or not mirror.exhausted:
+                    self._list_len = max(getattr(self, "_list_len", 0), min(M, 2 * max(self.head_capacity_last)))
+                    return out
+                m_use = M
         # H*base > 4096 (budget 2048: M is the whole row, a top-M list would be a full sort).  What :706-719 consume of the
         # order are selections and counts: the budgets come from histograms over the un-sorted rows (pkv_ada_budget_rows),
         # then every head's first cap_h entries of the canonical order from one top-k launch with per-head k.  Rows or

@@ -31,7 +31,7 @@ def test_header_symbols_exported(P):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/pkv.h but not exported by libpkv.so"
     assert set(P._native.EXPORTED) == declared
-    assert lib.pkv_version() == 101
+    assert lib.pkv_version() == 102
     # hidden visibility + export map: the dynamic symbol table is the C ABI and nothing else
     import shutil
     import subprocess

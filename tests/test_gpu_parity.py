@@ -677,6 +677,47 @@ def test_adakv_cluster_metadata_and_consistency(P):
     assert torch.equal(kf2.cpu(), k2.reshape(-1, 128)) and cl2.head_lens.cpu().tolist() == [40, 40]
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_adakv_short_candidate_lists_are_exact_or_repeated(P, dt):
+    """Round 4: Ada-SnapKV's per-head candidate lists start at ``config.ada_short_lists`` x base entries instead of
+    min(L, H*base).  Lists that long either decide everything (no list runs out at the threshold) or the kernel says so and
+    the call is repeated with the full length: outputs and metadata identical to the full-length path for every factor,
+    including factor 1 (every head above its base budget exhausts its list) and a prompt where ONE head owns almost the
+    whole budget; the cluster remembers the length it needed."""
+    from pyramidkv_amd import config as cfg
+    H, S, w, cap = 16, 6000, 8, 72
+    old = cfg.ada_short_lists
+    try:
+        for skew in (False, True):
+            q, k, v = make_qkv(1, H, S, 128, dt, "gauss", 71)
+            if skew:                      # head 3 looks at ~1500 keys as hard as the others look at their best few
+                k[0, 3, 500:2000] += 0.9 * q[0, 3, -1]
+            qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+            outs = {}
+            for factor in (0, 1, 2, 8):
+                cfg.ada_short_lists = factor
+                cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+                kf, vf = cl.update_kv(kd, qd, vd)
+                outs[factor] = (kf.cpu(), vf.cpu(), cl.head_lens.cpu().tolist(), cl.cu_klen.cpu().tolist(), cl.klen_sum, cl.max_seqlen_k)
+                if factor:
+                    M = min(S - w, H * (cap - w))
+                    assert cl._list_len >= min(M, 2 * max(cl.head_capacity_last))
+                    kf2, vf2 = cl.update_kv(kd, qd, vd)                  # second call of the same cluster: the remembered length
+                    assert torch.equal(kf2.cpu(), outs[factor][0]) and torch.equal(vf2.cpu(), outs[factor][1])
+            for factor in (1, 2, 8):
+                a, b = outs[0], outs[factor]
+                assert a[2:] == b[2:], (skew, factor)
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (skew, factor)
+            kr, vr, meta = O.adakv_update_kv(k, q, v, w, cap, 7, "maxpool", 0.2, True)
+            sg = P.ops.score_window(qd, kd, w, "maxpool", 7, "mean").cpu()[0]
+            _, caps = O.adakv_head_capacity(sg[None], cap - w, 0.2, True)            # budgets of the kernel's own scores
+            assert [c + w for c in caps[0].tolist()] == outs[0][2]
+            if skew:
+                assert max(outs[0][2]) > 4 * (cap - w)                               # the planted head really took several budgets
+    finally:
+        cfg.ada_short_lists = old
+
+
 def test_adakv_randomised_configs(P):
     """24 seeded random Ada-SnapKV configurations (heads, S, window, pooling, budget, floor, normalize, dtype): the head
     budgets computed on the device from the kernel's own scores equal the oracle's budget arithmetic on those same
