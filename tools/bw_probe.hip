@@ -189,6 +189,22 @@ int main() {
     PROBE("glds_nt", glds_kernel<2>);
 #undef PROBE
   }
+  // Re-reading a buffer that fits the 256 MB Infinity Cache (MALL): the rate a SECOND pass over one layer's K would see
+  // (16.8 MB = the logits of a layer, 67 MB = un-expanded K at S = 32k, 134 MB, 268 MB = expanded K).  Back-to-back launches
+  // over the same bytes, one-pass grids; "cold" = the same launch right after 1 GiB of other traffic.
+  for (size_t mb : {(size_t)16, (size_t)64, (size_t)128, (size_t)256}) {
+    const size_t nn = mb * 1024 * 1024 / 16;
+    const dim3 g((nn + 2047) / 2048), b(256);
+    float warm = time_ms([&] { hipLaunchKernelGGL((read_kernel<8, false>), g, b, 0, 0, src, nn, sink); });
+    float warm_nt = time_ms([&] { hipLaunchKernelGGL((read_kernel<8, true>), g, b, 0, 0, src, nn, sink); });
+    float cold = time_ms([&] {
+      hipLaunchKernelGGL((read_kernel<8, true>), dim3(4096), dim3(256), 0, 0, src + nn, n - nn, sink);     // evict
+      hipLaunchKernelGGL((read_kernel<8, false>), g, b, 0, 0, src, nn, sink);
+    }, 10);
+    float evict = time_ms([&] { hipLaunchKernelGGL((read_kernel<8, true>), dim3(4096), dim3(256), 0, 0, src + nn, n - nn, sink); }, 10);
+    printf(" \"reread_%zuMiB\": {\"warm_GBps\": %.0f, \"warm_nt_GBps\": %.0f, \"warm_us\": %.1f, \"after_1GiB_of_other_reads_us\": %.1f},\n",
+           mb, nn * 16.0 / warm / 1e6, nn * 16.0 / warm_nt / 1e6, warm * 1e3, (cold - evict) * 1e3);
+  }
   printf(" \"bytes\": %zu\n}\n", bytes);
   return 0;
 }
