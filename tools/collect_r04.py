@@ -247,6 +247,12 @@ if os.path.exists(mb) and os.path.getsize(mb):
 abdir = os.path.join(P, "ab")
 if os.path.isdir(abdir):
     lines += ["## Same-session A/B files of this round (`ab/`)\n"] + ["* `ab/%s`" % f_ for f_ in sorted(os.listdir(abdir))] + [""]
+extra = [("prof_ada_bench_kernel_stats.csv", "rocprofv3 --kernel-trace --stats -- python tools/ada_bench.py (Ada-SnapKV / HeadKV, S = 8192 and 32768, budgets 128 and 2048)"),
+         ("prof_h2o_S8192_kernel_stats.csv", "rocprofv3 --kernel-trace --stats -- python tools/h2o_only.py 8192"),
+         ("bench_default_flags.json", "python bench.py (no flags: the driver's N = 1 form) on the final kernel sources")]
+have = [(f_, d_) for f_, d_ in extra if os.path.exists(os.path.join(P, f_))]
+if have:
+    lines += ["## Further files of this round (own short sessions)\n"] + ["* `%s` - %s" % fd for fd in have] + [""]
 sm = os.path.join(G, "smoke.log")
 if os.path.exists(sm):
     shutil.copy(sm, os.path.join(P, "smoke.log"))
