@@ -171,6 +171,20 @@ def topk_fits(rows: int, L: int, k: int) -> bool:
     return N.lib.pkv_topk_workspace_bytes(rows, L, k) == 0
 
 
+def _one_topk_workgroup(L: int, k: int) -> bool:
+    """The LDS budget of topk_kernel (csrc/pkv_topk.hip topk_lds_bytes): the row as 16-bit keys + the
+    selection list (rounded up to a power of two beyond 4096 entries) in 160 KB.  k > 16 384 never fits."""
+    lw = max(512, -(-(-(-L // 16)) // 512) * 512)
+    kpad = (k + 15) & ~15 if k <= 4096 else 1 << (k - 1).bit_length()
+    return 16 * lw <= 65536 and 2 * 16 * lw + 4 * max(kpad, 8192) + 4 * 256 + 4 * 64 <= 160 * 1024
+
+
+def _needs_full_sort(L: int, k: int, dtype) -> bool:
+    """Budgets beyond one top-k workgroup on rows the sort kernel holds (k in the tens of thousands at S <= 32k: nothing the
+    runners use, but the reference takes any k <= L): the selection is the first k entries of the complete canonical order."""
+    return k > 4096 and dtype != torch.float32 and L <= 32768 and not _one_topk_workgroup(L, k)
+
+
 def topk(scores: torch.Tensor, k: int, k_per_row: Optional[torch.Tensor] = None) -> torch.Tensor:
     """pyramidkv_utils.py:334.  scores [..., L] (16-bit) -> int32 [..., k], (value desc, index asc).  ``k_per_row`` (device
     int32, one entry per row, each <= k): row r gets only its first k_per_row[r] entries (the rest of the row is unspecified) -
@@ -240,6 +254,13 @@ def compress(q, k, v, window: int, topk_k: int, pooling, kernel_size: int, scale
     _require_gpu(q, k, v)
     q, k, v = _rowmajor(q), _rowmajor(k), _rowmajor(v)
     B, H, S, D = q.shape
+    if _needs_full_sort(S - window, topk_k, q.dtype):
+        idx = select(q, k, window, topk_k, pooling, kernel_size, scale_mode, kv_group, h2o)
+        ko, vo = gather_compact(k, v, idx, window, kv_group)
+        if idx_out is not None:
+            idx_out.view(B, H, topk_k).copy_(idx)
+            return ko, vo, idx_out
+        return (ko, vo, idx) if return_indices else (ko, vo)
     with _DeviceGuard(k.device):
         d, nb = _scoring_desc(q, k, v, window, None if h2o else pooling, kernel_size, "sum", scale_mode, topk_k, kv_group)
         ws, st = _workspace_and_stream(nb, k.device)
@@ -264,6 +285,12 @@ def select(q, k, window: int, topk_k: int, pooling, kernel_size: int, scale_mode
     _require_gpu(q, k)
     q, k = _rowmajor(q), _rowmajor(k)
     B, H = q.shape[0], q.shape[1]
+    L = q.shape[2] - window
+    if _needs_full_sort(L, topk_k, q.dtype):
+        scores = score_h2o(q, k, window, scale_mode=scale_mode, kv_group=kv_group) if h2o else \
+            score_window(q, k, window, pooling, kernel_size, "sum", scale_mode, kv_group=kv_group)
+        order, _ = sort_rows(scores.reshape(B * H, L), want_values=False)
+        return order[:, :topk_k].reshape(B, H, topk_k).contiguous()
     with torch.cuda.device(k.device):
         d = make_desc(q, k, None, window, None if h2o else pooling, kernel_size, "sum", scale_mode, topk_k, kv_group)
         ws = workspace(N.lib.pkv_workspace_bytes(d), k.device)

@@ -546,6 +546,34 @@ def test_cluster_index_out_receives_the_selected_indices(P):
     assert kc.shape == (2, 8, kk + w, 128)
 
 
+def test_budget_beyond_one_topk_workgroup_takes_the_full_sort(P):
+    """Budgets above 16 384 past tokens (nothing the runners use; the reference takes any k <= L): the selection list no longer
+    fits one top-k workgroup next to the row, so the host takes the first k entries of the complete canonical order
+    (pkv_sort_rows, rows <= 32 768) - found by tools/parity_fuzz.py in round 4, where these budgets still raised."""
+    S, w = 20011, 8
+    q, k, v = make_qkv(1, 4, S, 128, "bf16", "gauss", 83)
+    for kk, g in ((17000, 1), (S - w, 2), (16385, 1)):
+        ks, vs = k[:, ::g].contiguous(), v[:, ::g].contiguous()
+        ke, ve = ks.repeat_interleave(g, 1), vs.repeat_interleave(g, 1)
+        qd, kd, vd = q.to(DEV), ks.to(DEV), vs.to(DEV)
+        kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk, "maxpool", 7, kv_group=g, return_indices=True)
+        sg = P.ops.score_window(qd, kd, w, "maxpool", 7, kv_group=g).cpu()
+        want = O.topk_canonical(sg, kk)
+        assert torch.equal(idx.cpu().long(), want)
+        kr, vr = O.gather_compact(ke, ve, want, w)
+        assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+        assert torch.equal(P.ops.select(qd, kd, w, kk, "maxpool", 7, kv_group=g).cpu().long(), want)
+    cl = P.SnapKVCluster(window_size=w, max_capacity_prompt=17000 + w, kernel_size=7, pooling="maxpool")
+    buf = torch.empty(1, 4, 17000, dtype=torch.int32, device=DEV)
+    cl.index_out = buf
+    kc2, vc2 = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV), None, 1)
+    sg = P.ops.score_window(q.to(DEV), k.to(DEV), w, "maxpool", 7).cpu()
+    want = O.topk_canonical(sg, 17000)
+    assert torch.equal(buf.cpu().long(), want)
+    kr, vr = O.gather_compact(k, v, want, w)
+    assert torch.equal(kc2.cpu(), kr) and torch.equal(vc2.cpu(), vr)
+
+
 def test_h2o_cluster(P):
     S, w, cap = 1024, 8, 64
     q, k, v = make_qkv(1, 4, S, 128, "bf16", "gauss", 55)

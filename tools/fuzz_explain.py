@@ -11,11 +11,12 @@ import pyramidkv_amd as P
 from inputs import make_qkv, bits, DTYPES
 from oracle import pkv_oracle as O
 seed, target = int(sys.argv[1]), int(sys.argv[2])
+smax = int(sys.argv[3]) if len(sys.argv) > 3 else 5000          # the third argument of the parity_fuzz.py run being replayed
 rng = np.random.RandomState(seed)
 n = 0
 while True:
     pol = str(rng.choice(["window", "window", "h2o", "adakv", "merge", "pyramid"]))
-    S = int(rng.randint(40, 5000)) if pol != "h2o" else int(rng.randint(40, 1800))
+    S = int(rng.randint(40, smax)) if pol != "h2o" else int(rng.randint(40, 1800))
     w = int(rng.choice([1, 4, 8, 8, 16, 32, 64]))
     if S <= w + 8:
         continue
@@ -25,7 +26,7 @@ while True:
     kind = ("gauss", "lattice", "planted")[int(rng.randint(0, 3))]
     pool, ks = [("maxpool", 7), ("avgpool", 5), ("maxpool", 17), ("avgpool", 13), (None, 1), ("maxpool", 3)][int(rng.randint(0, 6))]
     L = S - w
-    kk = int(rng.randint(1, L + 1)) if rng.rand() < 0.7 else int(rng.choice([1, L, min(L, 512), min(L, 513), min(L, 2040)]))
+    kk = int(rng.randint(1, L + 1)) if rng.rand() < 0.7 else int(rng.choice([1, L, min(L, 512), min(L, 513), min(L, 2040), min(L, 4096), min(L, 4097)]))
     dseed = int(rng.randint(0, 1 << 30))
     if n == target:
         break

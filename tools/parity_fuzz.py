@@ -5,7 +5,7 @@ loose bar): pooled scores vs the oracle - the suite's fixed seeds stay within 1 
 seeds a 1-ulp flip of a LOGIT (fp32 accumulation order of q.k, MFMA vs ATen: ~1e-6 of the elements) moves that probability by
 ulp(x) relative = about |x| ulps of the probability, diluted by the window-row sum (w = 8: 1-2 ulp of the score; w = 1: up to
 |x| ~ 3-8), so this tool fails a case only beyond 8 ulp or 2 % of the elements and reports how often 1 ulp / 0.5 % were exceeded.  The suite's randomised tests use fixed seeds; this walks new ones.
-  python tools/parity_fuzz.py [seconds] [seed]"""
+  python tools/parity_fuzz.py [seconds] [seed] [longest prompt, default 5000]"""
 import os, sys, time, json
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,6 +28,7 @@ def score_diff(a, b):
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+smax = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 rng = np.random.RandomState(seed)
 t0, n, fails, kinds = time.time(), 0, [], {}
 fp = dict(score_checks=0, over_1ulp=0, over_half_percent=0, max_ulp=0, max_frac=0.0)
@@ -40,7 +41,7 @@ def fp_check(got, want, what):
     assert mx <= 8 and frac <= 2e-2, (what, frac, mx)
 while time.time() - t0 < budget:
     pol = str(rng.choice(["window", "window", "h2o", "adakv", "merge", "pyramid"]))
-    S = int(rng.randint(40, 5000)) if pol != "h2o" else int(rng.randint(40, 1800))
+    S = int(rng.randint(40, smax)) if pol != "h2o" else int(rng.randint(40, 1800))
     w = int(rng.choice([1, 4, 8, 8, 16, 32, 64]))
     if S <= w + 8:
         continue
@@ -51,7 +52,7 @@ while time.time() - t0 < budget:
     kind = ("gauss", "lattice", "planted")[int(rng.randint(0, 3))]
     pool, ks = [("maxpool", 7), ("avgpool", 5), ("maxpool", 17), ("avgpool", 13), (None, 1), ("maxpool", 3)][int(rng.randint(0, 6))]
     L = S - w
-    kk = int(rng.randint(1, L + 1)) if rng.rand() < 0.7 else int(rng.choice([1, L, min(L, 512), min(L, 513), min(L, 2040)]))
+    kk = int(rng.randint(1, L + 1)) if rng.rand() < 0.7 else int(rng.choice([1, L, min(L, 512), min(L, 513), min(L, 2040), min(L, 4096), min(L, 4097)]))
     q, k, v = make_qkv(B, H, S, 128, dt, kind, int(rng.randint(0, 1 << 30)))
     ku, vu = k[:, ::G].contiguous(), v[:, ::G].contiguous()
     ke, ve = ku.repeat_interleave(G, dim=1), vu.repeat_interleave(G, dim=1)
