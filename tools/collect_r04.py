@@ -249,7 +249,9 @@ if os.path.isdir(abdir):
     lines += ["## Same-session A/B files of this round (`ab/`)\n"] + ["* `ab/%s`" % f_ for f_ in sorted(os.listdir(abdir))] + [""]
 extra = [("prof_ada_bench_kernel_stats.csv", "rocprofv3 --kernel-trace --stats -- python tools/ada_bench.py (Ada-SnapKV / HeadKV, S = 8192 and 32768, budgets 128 and 2048)"),
          ("prof_h2o_S8192_kernel_stats.csv", "rocprofv3 --kernel-trace --stats -- python tools/h2o_only.py 8192"),
-         ("bench_default_flags.json", "python bench.py (no flags: the driver's N = 1 form) on the final kernel sources")]
+         ("bench_default_flags.json", "python bench.py (no flags: the driver's N = 1 form) on the final kernel sources"),
+         ("parity_fuzz.txt", "tools/parity_fuzz.py over three new seeds + the replayed outlier (tools/fuzz_explain.py)"),
+         ("pytest_after_full_session.txt", "the one GPU test added after the full session (host-side change), run in its own call")]
 have = [(f_, d_) for f_, d_ in extra if os.path.exists(os.path.join(P, f_))]
 if have:
     lines += ["## Further files of this round (own short sessions)\n"] + ["* `%s` - %s" % fd for fd in have] + [""]
