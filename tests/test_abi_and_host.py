@@ -311,3 +311,21 @@ def test_abi_argument_fuzz_never_crashes(P):
         assert isinstance(N.lib.pkv_strerror(rc), bytes)
         assert N.lib.pkv_workspace_bytes(d) >= 0
     assert {-1, -2, -5} <= seen
+
+
+def test_full_sort_route_only_for_budgets_beyond_one_topk_workgroup():
+    """ops._needs_full_sort (round 4): budgets the runners use (<= 4096) never leave the top-k kernel; a selection list beyond
+    one workgroup's LDS (k > 16 384, or a large k next to a long row) on rows the sort kernel holds does; fp32 and rows beyond
+    32 768 scores keep their own paths."""
+    import torch
+    from pyramidkv_amd import ops
+    for L in (100, 4088, 8184, 32760, 57344):
+        for k in (1, 17, 120, 2040, 4096):
+            if k <= L:
+                assert not ops._needs_full_sort(L, k, torch.bfloat16)
+                assert ops._one_topk_workgroup(L, k)
+    assert ops._one_topk_workgroup(32760, 16384) and not ops._one_topk_workgroup(32760, 16385)
+    assert not ops._one_topk_workgroup(57345, 100)
+    assert ops._needs_full_sort(20003, 17000, torch.bfloat16) and ops._needs_full_sort(32760, 32760, torch.float16)
+    assert not ops._needs_full_sort(20003, 17000, torch.float32)          # fp32 keys: topk_f32 (k <= 4096) answers for itself
+    assert not ops._needs_full_sort(40000, 17000, torch.bfloat16)         # beyond pkv_sort_rows' 32 768: the C ABI answers (UNSUPPORTED)
