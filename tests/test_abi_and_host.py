@@ -329,3 +329,51 @@ def test_full_sort_route_only_for_budgets_beyond_one_topk_workgroup():
     assert ops._needs_full_sort(20003, 17000, torch.bfloat16) and ops._needs_full_sort(32760, 32760, torch.float16)
     assert not ops._needs_full_sort(20003, 17000, torch.float32)          # fp32 keys: topk_f32 (k <= 4096) answers for itself
     assert not ops._needs_full_sort(40000, 17000, torch.bfloat16)         # beyond pkv_sort_rows' 32 768: the C ABI answers (UNSUPPORTED)
+
+
+def test_adakv_short_list_retry_logic_on_the_host(monkeypatch):
+    """AdaKVCluster's short-candidate-list protocol without a GPU (round 4): the host mirror's sequence word carries the kernel's
+    "a list ran out" bit; update_kv repeats the call once with the full length, then remembers twice the largest share."""
+    import numpy as np
+    import torch
+    import pyramidkv_amd.pyramidkv_utils as U
+    from pyramidkv_amd import config as cfg
+
+    m = object.__new__(U._HostMirror)                 # the real class minus its pinned allocation (no accelerator here)
+    m.np = np.zeros(5, dtype=np.int32); m.t = torch.from_numpy(m.np); m.H, m.seq = 4, 0
+    seq = m.next_seq()
+    m.np[:4] = [3, 9, 1, 7]; m.np[4] = seq | 0x40000000
+    assert m.wait("cpu") == [3, 9, 1, 7] and m.exhausted
+    seq = m.next_seq(); m.np[4] = seq
+    assert m.wait("cpu") == [3, 9, 1, 7] and not m.exhausted
+
+    calls = []
+    H, S, w, cap = 4, 1000, 8, 40                      # base 32: M = min(992, 128) = 128, first try 2 x 32 = 64 entries
+    cl = U.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+    cl._mirror = m
+
+    def fake_select(q, k, window, pooling, ks, M, base, floor, norm, **kw):
+        calls.append(M)
+        return torch.zeros(H, M, dtype=torch.int32), torch.zeros(H, dtype=torch.int32), None, None, None
+
+    def fake_flat(self, key_states, value_states, sorted_idx, cap_dev, num_heads, meta=None, rows_bound=None, mirror=None, caps_host=None):
+        mirror.exhausted = sorted_idx.shape[1] < 100          # the "kernel": lists shorter than 100 entries run out
+        self.head_capacity_last = [30, 90, 5, 3]
+        return "K", "V"
+    monkeypatch.setattr(U.ops, "ada_select", fake_select)
+    monkeypatch.setattr(U._FlatPolicy, "_flat_from_capacity", fake_flat)
+    monkeypatch.setattr(U, "_fit_group", lambda k, v, g, w_: (k, v, g))
+    monkeypatch.setattr(U, "_unexpanded_group", lambda k, q: 1)
+    monkeypatch.setattr(cfg, "host_poll", True)
+    monkeypatch.setattr(cfg, "ada_short_lists", 2)
+    q = torch.zeros(1, H, S, 16, dtype=torch.bfloat16)
+    assert cl.update_kv(q, q, q) == ("K", "V")
+    assert calls == [64, 128] and cl._list_len == 128          # ran out at 64 -> full length; remembers min(M, 2 x 90)
+    calls.clear()
+    assert cl.update_kv(q, q, q) == ("K", "V") and calls == [128]
+    monkeypatch.setattr(cfg, "ada_short_lists", 0)
+    cl2 = U.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+    cl2._mirror = m
+    calls.clear()
+    cl2.update_kv(q, q, q)
+    assert calls == [128]                                        # knob off: always the full length
