@@ -32,6 +32,7 @@ int main() {
 
   pkv_desc d;
   memset(&d, 0, sizeof d);
+  d.struct_size = sizeof d;      // the layout THIS host was compiled against: the library reads no further
   d.dtype = PKV_BF16; d.B = B; d.H = H; d.S = S; d.D = D; d.kv_group = 1;
   const int64_t strides[3] = {(int64_t)H * S * D, (int64_t)S * D, D};
   for (int i = 0; i < 3; ++i) d.q_stride[i] = d.k_stride[i] = d.v_stride[i] = strides[i];
@@ -106,6 +107,8 @@ int main() {
   // error convention: a bad descriptor is reported, nothing aborts
   pkv_desc e = d; e.D = 100;
   if (pkv_compress(&e, q, kk, v, ko, vo, idx, ws, wsb, stream) != PKV_ERR_SHAPE) { printf("D=100 not rejected\n"); bad = 1; }
+  e = d; e.struct_size = 0;      // a host that never heard of struct_size (or an uninitialised descriptor)
+  if (pkv_compress(&e, q, kk, v, ko, vo, idx, ws, wsb, stream) != PKV_ERR_ABI) { printf("struct_size 0 not rejected\n"); bad = 1; }
   printf(bad ? "host_cabi: FAILED\n" : "host_cabi: ok (pkv_version %d, %d heads x top-%d of %d, workspace %zu bytes)\n", pkv_version(), B * H, k, L, wsb);
   return bad;
 }

@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PKV_VERSION 102 /* 0.1.2: pkv_ada_select accepts short candidate lists (with a host mirror); 0.1.1: pkv_desc.tie_order */
+#define PKV_VERSION 200 /* 0.2.0: pkv_desc starts with struct_size (the struct can grow without breaking hosts built against an
+                           older header); pkv_ada_select's budget step is one launch; 0.1.2: short Ada-SnapKV candidate lists */
 /* libpkv.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table (plus nothing). */
 #define PKV_API __attribute__((visibility("default")))
 
@@ -41,7 +42,8 @@ enum pkv_status {
   PKV_ERR_UNSUPPORTED = -5, /* valid request outside the limits of this build */
   PKV_ERR_HIP = -6,         /* a HIP runtime call failed; see pkv_last_hip_error() */
   PKV_ERR_NULL = -7,
-  PKV_ERR_COLLECTIVE = -8   /* an RCCL call failed; see pkv_last_nccl_error() */
+  PKV_ERR_COLLECTIVE = -8,  /* an RCCL call failed; see pkv_last_nccl_error() */
+  PKV_ERR_ABI = -9          /* pkv_desc.struct_size is not a size this library knows (host built against another pkv.h) */
 };
 
 /* PKV_F32: pkv_score_window, pkv_score_h2o, pkv_topk(_ws), pkv_gather_compact, pkv_gather_streaming, pkv_gather_flat,
@@ -60,11 +62,18 @@ enum pkv_scale { PKV_SCALE_DIV = 0, PKV_SCALE_RCP = 1 };
  * PyramidKV's upper layers (k = 17..32) then sit in the order of a reference run on the same GPU.  Same token set either way. */
 enum pkv_tie { PKV_TIE_CANONICAL = 0, PKV_TIE_ATEN_ROCM = 1 };
 
+/* The descriptor GROWS at its end from version to version.  The caller stores sizeof(pkv_desc) of the header it was compiled
+ * against in struct_size; the library reads exactly that many bytes - never more - and takes every field the caller's
+ * struct does not have yet as 0 (each new field is defined so that 0 = the behaviour before it existed).  A size below
+ * PKV_DESC_MIN_SIZE or above the library's own sizeof(pkv_desc) returns PKV_ERR_ABI from every entry point that takes a
+ * descriptor (pkv_workspace_bytes / pkv_merge_workspace_bytes return 0). */
 typedef struct pkv_desc {
+  uint32_t struct_size; /* sizeof(pkv_desc) as the CALLER compiled it */
   int32_t dtype;        /* pkv_dtype of q,k,v and of every score buffer */
   int32_t B, H, S, D;   /* H = number of query heads; D = 64, 128 or 256 (all entry points) */
   int32_t kv_group;     /* 1: k,v have H heads (post-repeat_kv, the reference contract).
                            g>1: k,v have H/g heads (un-expanded GQA); head h reads kv head h/g */
+  int32_t reserved0;    /* must be 0 (keeps the strides 8-byte aligned without implicit padding) */
   int64_t q_stride[3];  /* element strides of q for b,h,s */
   int64_t k_stride[3];
   int64_t v_stride[3];
@@ -74,8 +83,12 @@ typedef struct pkv_desc {
   int32_t reduce;       /* pkv_reduce: SUM for SnapKV/PyramidKV (:327), MEAN for AdaKV/HeadKV (:661) */
   int32_t scale_mode;   /* pkv_scale */
   int32_t topk;         /* k = past tokens kept per head, 1..S-window (host-resolved per layer) */
-  int32_t tie_order;    /* a pkv_tie value, honoured by the selecting entry points pkv_compress, pkv_compress_h2o, pkv_select on bf16 / fp16 scores; 0 = canonical */
+  int32_t tie_order;    /* a pkv_tie value, honoured by the selecting entry points pkv_compress, pkv_compress_h2o, pkv_select on
+                           bf16 / fp16 scores; 0 = canonical; any other value than 0 / 1 returns PKV_ERR_SHAPE from every entry
+                           point that validates the descriptor (since 0.1.1) */
+  int32_t reserved1;    /* must be 0 (explicit tail padding: sizeof(pkv_desc) is a multiple of 8 without implicit padding) */
 } pkv_desc;
+#define PKV_DESC_MIN_SIZE 136u /* sizeof(pkv_desc) of 0.2.0, the first layout that carries struct_size */
 
 PKV_API int pkv_version(void);
 PKV_API const char* pkv_strerror(int status);

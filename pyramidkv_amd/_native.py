@@ -22,14 +22,25 @@ TIE = {"canonical": 0, "aten_rocm": 1}
 KERNEL_NAMES = ["logits", "finalize", "topk", "gather", "h2o_stats", "h2o_colsum", "sort", "budget"]
 
 
+PKV_VERSION = 200            # include/pkv.h PKV_VERSION this binding was written against (checked when the library loads)
+
+
 class PkvDesc(C.Structure):
+    """struct pkv_desc of include/pkv.h (tests/test_abi_and_host.py compares the two field by field)."""
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("S", C.c_int32), ("D", C.c_int32),
-        ("kv_group", C.c_int32),
+        ("kv_group", C.c_int32), ("reserved0", C.c_int32),
         ("q_stride", C.c_int64 * 3), ("k_stride", C.c_int64 * 3), ("v_stride", C.c_int64 * 3),
         ("window", C.c_int32), ("pool_kind", C.c_int32), ("pool_kernel", C.c_int32),
         ("reduce", C.c_int32), ("scale_mode", C.c_int32), ("topk", C.c_int32), ("tie_order", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if not self.struct_size:                 # the size of THIS layout: what the library is allowed to read
+            self.struct_size = C.sizeof(PkvDesc)
 
 
 class PkvError(RuntimeError):
@@ -43,6 +54,12 @@ def _load():
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C pyramidkv_amd/csrc`). "
             "pyramidkv_amd has no CPU/PyTorch fallback.")
     lib = C.CDLL(LIB_PATH)
+    lib.pkv_version.restype = C.c_int
+    have = lib.pkv_version()
+    if have != PKV_VERSION:          # libpkv.so is built in-tree and git-ignored: a stale build must not be driven by newer Python
+        raise ImportError(
+            f"{LIB_PATH} reports PKV_VERSION {have}, this package binds version {PKV_VERSION} (include/pkv.h): rebuild it with "
+            "`make -C pyramidkv_amd/csrc clean all` or `python -c 'import __graft_entry__ as g; g.build()'`")
     vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     dp = C.POINTER(PkvDesc)
     sig = {
@@ -99,7 +116,7 @@ def check(rc: int, what: str = "") -> None:
         msg += f" (hipError {lib.pkv_last_hip_error()})"
     if rc == -8:
         msg += f" (ncclResult {lib.pkv_last_nccl_error()})"
-    if rc in (-1, -2, -3, -5):
+    if rc in (-1, -2, -3, -5, -9):
         raise ValueError(f"libpkv {what}: {msg}")
     raise PkvError(f"libpkv {what}: {msg}")
 

@@ -6,6 +6,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <mutex>
 #include <vector>
@@ -89,6 +90,27 @@ struct ProfScope {
 };
 
 // ---- validation ------------------------------------------------------------------------------
+static_assert(sizeof(pkv_desc) == 136 && sizeof(pkv_desc) >= PKV_DESC_MIN_SIZE, "pkv_desc layout changed: bump PKV_VERSION, keep PKV_DESC_MIN_SIZE");
+
+// The caller's descriptor -> the library's own struct: exactly `struct_size` bytes are read (the size of the struct the HOST
+// was compiled against), fields the host does not have yet are 0.  Every entry point works on the copy.
+int load_desc(const pkv_desc* in, pkv_desc* out) {
+  if (!in) return PKV_ERR_NULL;
+  const uint32_t n = in->struct_size;
+  if (n < PKV_DESC_MIN_SIZE || n > sizeof(pkv_desc) || (n & 3u)) return PKV_ERR_ABI;
+  memset(out, 0, sizeof(pkv_desc));
+  memcpy(out, in, n);
+  out->struct_size = (uint32_t)sizeof(pkv_desc);
+  if (out->reserved0 != 0 || out->reserved1 != 0) return PKV_ERR_ABI;
+  return PKV_OK;
+}
+#define PKV_LOAD_DESC(d, on_fail)                                   \
+  pkv_desc d##_own;                                                 \
+  {                                                                 \
+    const int rc_ld = load_desc(d, &d##_own);                       \
+    if (rc_ld) return on_fail;                                      \
+  }                                                                 \
+  d = &d##_own
 // f32_ok: the entry point has an fp32 path (window scores, top-k, dense / streaming gather); every other one answers
 // PKV_ERR_UNSUPPORTED for fp32 tensors
 int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true, bool f32_ok = false) {
@@ -362,6 +384,7 @@ int do_gather(const GatherParams& g, int max_rows, hipStream_t st) {
 
 int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, const void* v, void* k_out,
                     void* v_out, int32_t* idx_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, true, true, true);
   if (rc) return rc;
   if (!q || !k || !v || !k_out || !v_out || !ws) return PKV_ERR_NULL;
@@ -406,6 +429,7 @@ const char* pkv_strerror(int s) {
     case PKV_ERR_HIP: return "HIP runtime error";
     case PKV_ERR_NULL: return "null pointer";
     case PKV_ERR_COLLECTIVE: return "RCCL call failed";
+    case PKV_ERR_ABI: return "pkv_desc.struct_size does not match a layout this library knows (host built against another pkv.h)";
     default: return "unknown status";
   }
 }
@@ -415,12 +439,14 @@ __attribute__((visibility("hidden"))) void pkv_set_last_hip_error(int e) { g_las
 
 
 size_t pkv_workspace_bytes(const pkv_desc* d) {
-  if (!d || d->S < 2 || d->window < 1 || d->window >= d->S || d->B < 1 || d->H < 1) return 0;
+  PKV_LOAD_DESC(d, 0);
+  if ( d->S < 2 || d->window < 1 || d->window >= d->S || d->B < 1 || d->H < 1) return 0;
   return ws_layout(d).total;
 }
 
 int pkv_score_window(const pkv_desc* d, const void* q, const void* k, void* scores_out,
                      int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, false, true, true);
   if (rc) return rc;
   if (!q || !k || !scores_out || !ws) return PKV_ERR_NULL;
@@ -433,6 +459,7 @@ int pkv_score_window(const pkv_desc* d, const void* q, const void* k, void* scor
 
 int pkv_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores_out,
                   int64_t scores_stride, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, false, true, true);
   if (rc) return rc;
   if (!q || !k || !scores_out || !ws) return PKV_ERR_NULL;
@@ -466,6 +493,7 @@ int pkv_topk_ws(int32_t dtype, int32_t rows, int32_t L, int32_t k, const void* s
 
 int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx,
                        int64_t idx_stride, void* k_out, void* v_out, pkv_stream_t stream) {
+  PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, true, false, true);
   if (rc) return rc;
   if (!k || !v || !idx || !k_out || !v_out) return PKV_ERR_NULL;
@@ -478,6 +506,7 @@ int pkv_gather_compact(const pkv_desc* d, const void* k, const void* v, const in
 
 int pkv_gather_streaming(const pkv_desc* d, const void* k, const void* v, void* k_out, void* v_out,
                          pkv_stream_t stream) {
+  PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, true, false, true);
   if (rc) return rc;
   if (!k || !v || !k_out || !v_out) return PKV_ERR_NULL;
@@ -499,6 +528,7 @@ int pkv_compress_h2o(const pkv_desc* d, const void* q, const void* k, const void
 // ---- selection only (score -> top-k), the front half of pkv_compress: what the merge path needs ----
 int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int32_t* idx_out, void* ws, size_t ws_bytes,
                pkv_stream_t stream) {
+  PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, true, true, true);
   if (rc) return rc;
   if (!q || !k || !idx_out || !ws) return PKV_ERR_NULL;
@@ -541,12 +571,14 @@ MergeWs merge_ws(const pkv_desc* d) {
 }  // namespace
 
 size_t pkv_merge_workspace_bytes(const pkv_desc* d) {
-  if (!d || d->S < 2 || d->window < 1 || d->window >= d->S || d->B < 1 || d->H < 1 || d->topk < 1) return 0;
+  PKV_LOAD_DESC(d, 0);
+  if ( d->S < 2 || d->window < 1 || d->window >= d->S || d->B < 1 || d->H < 1 || d->topk < 1) return 0;
   return merge_ws(d).total;
 }
 
 int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx, int64_t idx_stride,
                       void* k_out, void* v_out, void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, true, false, true);
   if (rc) return rc;
   if (!k || !v || !idx || !k_out || !v_out || !ws) return PKV_ERR_NULL;
@@ -684,6 +716,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
                    int32_t normalize, const int32_t* given_capacity, int32_t* top_idx, int32_t* head_capacity,
                    int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens, int32_t* host_mirror, int32_t host_seq,
                    void* ws, size_t ws_bytes, pkv_stream_t stream) {
+  PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, true);
   if (rc) return rc;
   if (d->B != 1) return PKV_ERR_SHAPE;                     // reference asserts bsz == 1 (:724)
@@ -738,6 +771,7 @@ int pkv_ada_metadata(int32_t H, int32_t window, const int32_t* head_capacity, in
 int pkv_gather_flat(const pkv_desc* d, const void* k, const void* v, const int32_t* sorted_idx,
                     int64_t idx_stride, const int32_t* head_capacity, const int32_t* cu_klen,
                     void* k_out, void* v_out, int64_t out_rows, pkv_stream_t stream) {
+  PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, false, false, true);      // fp32 rows move as 2D 16-bit elements (make_gather)
   if (rc) return rc;
   if (d->B != 1) return PKV_ERR_SHAPE;   // reference asserts bsz == 1 (:724)

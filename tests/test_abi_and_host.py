@@ -31,7 +31,7 @@ def test_header_symbols_exported(P):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/pkv.h but not exported by libpkv.so"
     assert set(P._native.EXPORTED) == declared
-    assert lib.pkv_version() == 102
+    assert lib.pkv_version() == P._native.PKV_VERSION == int(re.search(r"#define PKV_VERSION (\d+)", hdr).group(1))
     # hidden visibility + export map: the dynamic symbol table is the C ABI and nothing else
     import shutil
     import subprocess
@@ -39,6 +39,109 @@ def test_header_symbols_exported(P):
         out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "pyramidkv_amd", "libpkv.so")], capture_output=True, text=True).stdout
         exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
         assert exported == declared, sorted(exported ^ declared)[:10]
+
+
+def _header_desc_fields():
+    """struct pkv_desc of include/pkv.h -> [(name, ctypes type)] in declaration order."""
+    hdr = open(os.path.join(ROOT, "include", "pkv.h")).read()
+    body = re.search(r"typedef struct pkv_desc \{(.*?)\} pkv_desc;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    ctype = {"uint32_t": ctypes.c_uint32, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64}
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ty, names = decl.split(None, 1)
+        for nm in names.split(","):
+            nm = nm.strip()
+            m = re.fullmatch(r"(\w+)\[(\d+)\]", nm)
+            fields.append((m.group(1), ctype[ty] * int(m.group(2))) if m else (nm, ctype[ty]))
+    return fields
+
+
+def _documented_binding():
+    """The ```python block of INTEGRATION.md section 2, executed verbatim from the repository root."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"## 2\. The binding itself.*?```python\n(.*?)```", md, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(block, "INTEGRATION.md#binding", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    return ns
+
+
+def test_documented_binding_matches_the_header(P):
+    """the binding a maintainer copies out of INTEGRATION.md, pyramidkv_amd/_native.py and include/pkv.h
+    describe the SAME struct - field order, types, sizeof (round 4's documented struct was 8 bytes short of the header's)."""
+    hdr = _header_desc_fields()
+
+    class FromHeader(ctypes.Structure):
+        _fields_ = hdr
+    size = int(re.search(r"#define PKV_DESC_MIN_SIZE (\d+)u", open(os.path.join(ROOT, "include", "pkv.h")).read()).group(1))
+    assert ctypes.sizeof(FromHeader) == size == 136
+    assert hdr[0] == ("struct_size", ctypes.c_uint32)
+    for who, cls in (("pyramidkv_amd/_native.py", P._native.PkvDesc), ("INTEGRATION.md", _documented_binding()["PkvDesc"])):
+        got = [(n, t) for n, t in cls._fields_]
+        assert [n for n, _ in got] == [n for n, _ in hdr], who
+        for (n, t), (_, th) in zip(got, hdr):
+            assert ctypes.sizeof(t) == ctypes.sizeof(th) and getattr(t, "_length_", 1) == getattr(th, "_length_", 1), (who, n)
+            assert getattr(cls, n).offset == getattr(FromHeader, n).offset, (who, n)
+        assert ctypes.sizeof(cls) == ctypes.sizeof(FromHeader), who
+    # no implicit padding anywhere: the explicit reserved words carry it
+    off = 0
+    for n, t in hdr:
+        assert getattr(FromHeader, n).offset == off, n
+        off += ctypes.sizeof(t)
+    assert off == ctypes.sizeof(FromHeader)
+
+
+def test_desc_struct_size_is_checked_and_nothing_is_read_past_it(P):
+    """pkv_desc.struct_size: an unknown size is PKV_ERR_ABI (-9) from every entry point that takes a descriptor, and the
+    library never reads beyond the size the caller states (garbage behind the struct changes nothing)."""
+    N = P._native
+    d = N.PkvDesc()
+    assert d.struct_size == ctypes.sizeof(N.PkvDesc) == 136
+    d.dtype, d.B, d.H, d.S, d.D, d.kv_group, d.window, d.topk = 0, 1, 2, 64, 128, 1, 8, 4
+    for i in range(3):
+        d.k_stride[i] = d.v_stride[i] = d.q_stride[i] = 128
+    good_ws = N.lib.pkv_workspace_bytes(d)
+    assert good_ws > 0 and N.lib.pkv_gather_streaming(d, None, 16, 16, 16, None) == -7     # descriptor accepted (null k)
+    calls = {
+        "pkv_score_window": lambda x: N.lib.pkv_score_window(x, 16, 16, 16, 64, 16, 1 << 30, None),
+        "pkv_score_h2o": lambda x: N.lib.pkv_score_h2o(x, 16, 16, 16, 64, 16, 1 << 30, None),
+        "pkv_gather_compact": lambda x: N.lib.pkv_gather_compact(x, 16, 16, 16, 4, 16, 16, None),
+        "pkv_gather_streaming": lambda x: N.lib.pkv_gather_streaming(x, 16, 16, 16, 16, None),
+        "pkv_compress": lambda x: N.lib.pkv_compress(x, 16, 16, 16, 16, 16, None, 16, 1 << 30, None),
+        "pkv_compress_h2o": lambda x: N.lib.pkv_compress_h2o(x, 16, 16, 16, 16, 16, None, 16, 1 << 30, None),
+        "pkv_select": lambda x: N.lib.pkv_select(x, 16, 16, 0, 16, 16, 1 << 30, None),
+        "pkv_merge_compact": lambda x: N.lib.pkv_merge_compact(x, 16, 16, 16, 4, 16, 16, 16, 1 << 30, None),
+        "pkv_ada_select": lambda x: N.lib.pkv_ada_select(x, 16, 16, 4, 0.2, 1, None, 16, 16, 16, 16, 16, None, 0, 16, 1 << 30, None),
+        "pkv_gather_flat": lambda x: N.lib.pkv_gather_flat(x, 16, 16, 16, 4, 16, 16, 16, 16, 0, None),
+    }
+    for bad in (0, 4, 128, 132, 140, 144, 1 << 20):
+        d.struct_size = bad
+        assert N.lib.pkv_workspace_bytes(d) == 0 and N.lib.pkv_merge_workspace_bytes(d) == 0, bad
+        for name, call in calls.items():
+            assert call(d) == -9, (name, bad)
+    d.struct_size = 136
+    d.reserved0 = 1
+    assert calls["pkv_compress"](d) == -9
+    d.reserved0, d.reserved1 = 0, 7
+    assert calls["pkv_gather_streaming"](d) == -9
+    d.reserved1 = 0
+    assert N.lib.pkv_strerror(-9).startswith(b"pkv_desc.struct_size")
+    # garbage behind the struct (what sank the round-3 binding against the round-4 library): not read
+    buf = (ctypes.c_ubyte * 200)(*([0xAB] * 200))
+    ctypes.memmove(buf, ctypes.byref(d), 136)
+    dp = ctypes.cast(buf, ctypes.POINTER(N.PkvDesc))
+    assert N.lib.pkv_workspace_bytes(dp) == good_ws
+    assert N.lib.pkv_gather_streaming(dp, None, 16, 16, 16, None) == -7
+    with pytest.raises(ValueError, match="struct_size"):
+        N.check(-9, "pkv_compress")
 
 
 def test_strerror_and_argument_validation_without_gpu(P):

@@ -873,6 +873,40 @@ def test_c_host_without_python_bindings(P):
 
 
 # ----------------------------------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_documented_binding_reproduces_snapkv_update_kv(P, dt):
+    """INTEGRATION.md section 2, run VERBATIM (its own ctypes struct, its own CDLL of pyramidkv_amd/libpkv.so - not
+    pyramidkv_amd._native): `snapkv_update_kv` == SnapKVCluster.update_kv (pyramidkv_utils.py:306-347) bit for bit on
+    margin-checked inputs, also for K / V handed over as transposed views (the n_rep == 1 case of SURVEY section 8b)."""
+    import re
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"## 2\. The binding itself.*?```python\n(.*?)```", md, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(block, "INTEGRATION.md#binding", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    assert ns["PkvDesc"] is not P._native.PkvDesc and ns["lib"] is not P._native.lib
+    w, cap, S = 8, 64, 4096
+    q, k, v = make_qkv(1, 8, S, 128, dt, "planted", 4242)
+    kr, vr, ridx = O.snapkv_update_kv(k, q, v, w, cap, 7, "maxpool", return_indices=True)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    kc, vc = ns["snapkv_update_kv"](kd, qd, vd, w, cap, 7, "maxpool")
+    torch.cuda.synchronize()
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+    vt = vd.transpose(1, 2).contiguous().transpose(1, 2)          # [B,H,S,D] view with strides [S*H*D, D, H*D, 1]
+    assert not vt.is_contiguous()
+    kc2, vc2 = ns["snapkv_update_kv"](kd, qd, vt, w, cap, 7, "maxpool")
+    torch.cuda.synchronize()
+    assert torch.equal(kc2.cpu(), kr) and torch.equal(vc2.cpu(), vr)
+    # the documented struct with garbage behind it (round 4's failure: the library read past a shorter struct)
+    import ctypes
+    d = ns["PkvDesc"](struct_size=0)
+    assert ns["lib"].pkv_workspace_bytes(ctypes.byref(d)) == 0
+
+
 def test_golden_fixtures_through_hip_path(P):
     """Outputs of the REAL reference (tests/golden, produced on CPU) vs the HIP path on the same inputs.
     The reference's CPU ``topk`` breaks ties arbitrarily, so the statement that can hold bit-for-bit is:
