@@ -267,7 +267,8 @@ def compress(q, k, v, window: int, topk_k: int, pooling, kernel_size: int, scale
         ko = torch.empty(B, H, topk_k + window, D, dtype=k.dtype, device=k.device)
         vo = torch.empty_like(ko)
         if idx_out is not None:
-            assert idx_out.dtype == torch.int32 and idx_out.is_contiguous() and idx_out.numel() == B * H * topk_k
+            if idx_out.dtype != torch.int32 or not idx_out.is_contiguous() or idx_out.numel() != B * H * topk_k:
+                raise ValueError("idx_out must be a contiguous int32 tensor of B*H*k elements")
             idx, return_indices = idx_out, True
         else:
             idx = torch.empty(B, H, topk_k, dtype=torch.int32, device=k.device) if return_indices else None

@@ -90,6 +90,9 @@ class _WindowPolicy:
     accepts_unexpanded_kv = True      # update_kv also takes K/V with H/g heads (before repeat_kv)
     # optional contiguous int32 [B, H, k] tensor: update_kv ALSO writes the selected indices there (a head-sharded host
     # all-gathers them, pyramidkv_amd/dist.py; bench.py reads them back for its parity block).  Not a reference attribute.
+    # Written on every path that SELECTS (plain gather and merge="pivot"); a call that selects nothing - the pass-through
+    # below max_capacity_prompt (:219,:315) or a pyramid layer with a budget of 0 past tokens - leaves it untouched, and a
+    # buffer whose size is not B*H*k raises.
     index_out = None
 
     def _compress(self, key_states, query_states, value_states, k, num_key_value_groups, h2o=False):
@@ -110,6 +113,10 @@ class _WindowPolicy:
             ks, vs = (key_states, value_states) if gu > 1 else (_dedup_view(key_states, g), _dedup_view(value_states, g))
             idx = ops.select(query_states, ks, self.window_size, k, self.pooling, self.kernel_size,
                              scale_mode=_cfg.scale_mode, kv_group=g, h2o=h2o)
+            if self.index_out is not None:
+                if self.index_out.dtype != torch.int32 or not self.index_out.is_contiguous() or self.index_out.numel() != idx.numel():
+                    raise ValueError("index_out must be a contiguous int32 tensor of B*H*k elements")
+                self.index_out.view_as(idx).copy_(idx)
             return ops.merge_compact(ks, vs, idx, self.window_size, kv_group=g)
         if gu > 1:
             return ops.compress(query_states, key_states, value_states, self.window_size, k, self.pooling,
@@ -481,7 +488,9 @@ class AdaKVCluster(_FlatPolicy):
             if key_states.dtype == torch.float32 or ops.topk_fits(num_heads, L, kmax):
                 try:
                     top_idx = ops.topk(attn_score, kmax, k_per_row=cap)
-                except ValueError:                                                   # fp32: capacities beyond 4096
+                except ValueError:
+                    if key_states.dtype != torch.float32:
+                        raise
                     raise ValueError("Ada-SnapKV on fp32 tensors: head capacities up to 4096 past tokens") from None
             else:
                 # rows / capacities beyond one top-k workgroup: the complete order once, the capacities already computed above

@@ -544,6 +544,19 @@ def test_cluster_index_out_receives_the_selected_indices(P):
             assert torch.equal(buf, idx0) and torch.equal(kc, kc0) and torch.equal(vc, vc0)
     kc, vc = cl.update_kv(kd, qd, vd, None, 1)                   # and without a sink nothing else changes
     assert kc.shape == (2, 8, kk + w, 128)
+    # merge="pivot" selects through pkv_select: the same indices land in index_out; a wrong-sized sink raises
+    cm = P.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool", merge="pivot")
+    buf = torch.full((2, 8, cap - w), -1, dtype=torch.int32, device=DEV)
+    cm.index_out = buf
+    cm.update_kv(kd, qd, vd, None, 1)
+    assert torch.equal(buf, P.ops.select(qd, kd, w, cap - w, "maxpool", 7))
+    cm.index_out = torch.empty(3, dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError, match="index_out"):
+        cm.update_kv(kd, qd, vd, None, 1)
+    cl.index_out = torch.empty(3, dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError, match="idx_out"):
+        cl.update_kv(kd, qd, vd, None, 1)
+    cl.index_out = None
 
 
 def test_budget_beyond_one_topk_workgroup_takes_the_full_sort(P):
