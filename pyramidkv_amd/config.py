@@ -18,7 +18,7 @@ host_poll = os.environ.get("PKV_HOST_POLL", "1") == "1"
 # Ada-SnapKV, H * base <= 4096: every head's list of candidates starts at this many times the base budget instead of
 # min(L, H * base) entries (exact: the kernel reports a list that ran out and the call is repeated with the full length);
 # 0 = always the full length.  Needs host_poll.
-ada_short_lists = int(os.environ.get("PKV_ADA_SHORT_LISTS", "8"))
+ada_short_lists = int(os.environ.get("PKV_ADA_SHORT_LISTS", "4"))
 
 # Order of equal scores in the selected rows: "canonical" = (value descending, index ascending), what PyTorch-ROCm's topk gives
 # for k > 32; "aten_rocm" additionally reproduces, for k <= 32, the order its unstable small-slice sort leaves them in - the

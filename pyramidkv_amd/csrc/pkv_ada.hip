@@ -188,6 +188,10 @@ __global__ __launch_bounds__(256) void ada_lo_kernel(BudgetParams p, AdaWs ws) {
   ws.cum_lo[h * 256 + tid] = count_ge<T>(v, p.L, ws.ratio[h], p.normalize, ((uint32_t)b1 << 8) | (uint32_t)tid);
 }
 
+template <int NW>
+__device__ __forceinline__ void ada_finish(const BudgetParams& p, int gt, int eq, float one_minus_floor, int window, int32_t* head_lens,
+                                           int32_t* cu_klen, int32_t* cu_headlens, int64_t* s_red, int* s_scan);
+
 // Final step, one workgroup: thread h owns head h.  gt_h = entries above the global threshold, eq_h = entries equal to it;
 // the ties are handed out in flattened (head-major) order: head h takes min(eq_h, need - ties taken by the heads before it),
 // an exclusive prefix sum over the heads.  Optionally writes the var-len metadata of :682-691 as well (one launch less).
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
   __shared__ int s_b;
   __shared__ int64_t s_red[4];
   __shared__ int s_scan[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int64_t total = (int64_t)p.H * p.base;
   const int b1 = find_level(ws.cum_hi, p.H, total, s_sum, &s_b, tid);
   const int b2 = find_level(ws.cum_lo, p.H, total, s_sum, &s_b, tid);
@@ -206,6 +210,30 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
     gt = b2 < 255 ? ws.cum_lo[tid * 256 + b2 + 1] : (b1 < 255 ? ws.cum_hi[tid * 256 + b1 + 1] : (ws.above_hi ? ws.above_hi[tid] : 0));
     eq = ws.cum_lo[tid * 256 + b2] - gt;
   }
+  ada_finish<4>(p, gt, eq, one_minus_floor, window, head_lens, cu_klen, cu_headlens, s_red, s_scan);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ada_fused_kernel (round 5): budgets + metadata of pkv_ada_select in ONE single-workgroup launch.
+// topk_kernel<T, true> left every head's descending list of RAW scores (the first L entries of :706's order) and the row
+// sums (:710) behind, H x L <= 45 056 entries: all of it fits the LDS of one 1024-thread workgroup, so the three launches
+// of the list path (ada_stats -> ada_lo -> ada_final, 18.7 us at H = 32: three dependent ~5 us kernels that each wait for
+// the previous one's tables in memory) become one launch without any table in memory and without a device-scope meeting
+// point (the last-block variant of round 4 lost to exactly that fence):
+//   wave w owns heads w, w + 16, ...: sum of the head's `base` largest scores -> ratio (:710) -> the list becomes the list
+//   of ADAPTIVE keys in place (:711) while the high-byte histogram is counted; exact two-level (8+8 bit) radix select of
+//   the (H*base)-th largest adaptive key over all heads (:712-713) = the global threshold T; per head the entries above /
+//   at T (:714-717); ties, capacities (:719), var-len metadata (:682-691) and the host mirror as in ada_final_kernel.
+// Same integers as the three-kernel path (tests compare both with the oracle).
+// ------------------------------------------------------------------------------------------------
+constexpr int ADA_FUSED_MAX_KEYS = 45056;       // 2 B each (88 KB) + two 32 KB counter arrays + ~6 KB of statics inside 160 KB
+
+// tail shared by ada_final_kernel and ada_fused_kernel: thread h < H holds (gt, eq) of head h; every thread of the workgroup calls
+template <int NW>
+__device__ __forceinline__ void ada_finish(const BudgetParams& p, int gt, int eq, float one_minus_floor, int window, int32_t* head_lens,
+                                           int32_t* cu_klen, int32_t* cu_headlens, int64_t* s_red, int* s_scan) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t total = (int64_t)p.H * p.base;
   // need = total - sum_h gt_h
   int64_t g = gt;
   for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
@@ -214,7 +242,10 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
   const uint32_t incl = wave_incl_scan_u32((uint32_t)eq);
   if (lane == 63) s_scan[wave] = (int)incl;
   __syncthreads();
-  const int64_t need = total - (s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+  int64_t above = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < NW; ++w2) above += s_red[w2];
+  const int64_t need = total - above;
   int64_t before = (int64_t)incl - eq;
   for (int w2 = 0; w2 < wave; ++w2) before += s_scan[w2];
   int cap = 0;
@@ -253,6 +284,105 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
     if (tid < p.H) { head_lens[tid] = n; cu_klen[tid] = off; if (cu_headlens) cu_headlens[tid] = off + n; }
     if (tid == p.H - 1) cu_klen[p.H] = off + n;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, const uint16_t* list, int Lpad, const double* rowsum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ada_smem[];
+  __shared__ __attribute__((aligned(16))) uint32_t hist[256];
+  __shared__ int misc[4];
+  __shared__ int s_gt[256], s_eq[256];
+  __shared__ double s_rs[256];
+  __shared__ int64_t s_red[TK_WAVES];
+  __shared__ int s_scan[TK_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, M = p.L;
+  const int nk = H * Lpad;                                         // Lpad is a multiple of 8
+  uint16_t* keys = reinterpret_cast<uint16_t*>(ada_smem);
+  uint32_t* X1 = reinterpret_cast<uint32_t*>(ada_smem + (((size_t)nk * 2 + 15) & ~(size_t)15));
+  uint32_t* X2 = X1 + TK_CNT_WORDS;
+  const uint32_t inc = lane < 32 ? 1u : 65536u;
+  const int cslot = lane & 31;
+  // every list and the 16 partial row sums of every head (thread h: head h) in flight together
+  double2 rp[TK_WAVES / 2];
+  if (p.normalize && tid < H) {
+#pragma unroll
+    for (int j = 0; j < TK_WAVES / 2; ++j) rp[j] = reinterpret_cast<const double2*>(rowsum + (int64_t)tid * TK_WAVES)[j];
+  }
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(list);
+    const int nv = nk >> 3;
+    for (int c0 = 0; c0 < nv; c0 += 8 * TK_THREADS) {
+      uint4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int c = c0 + j * TK_THREADS + tid; t[j] = src[c < nv ? c : 0]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int c = c0 + j * TK_THREADS + tid; if (c < nv) reinterpret_cast<uint4*>(keys)[c] = t[j]; }
+    }
+  }
+  for (int i = tid; i < 2 * TK_CNT_WORDS; i += TK_THREADS) X1[i] = 0;     // X1 and X2 are adjacent
+  if (p.normalize && tid < H) {                                           // the 16 partials in wave order: a fixed order, run-to-run identical
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < TK_WAVES / 2; ++j) { a += rp[j].x; a += rp[j].y; }
+    s_rs[tid] = a;
+  }
+  __syncthreads();
+  // ---- per head (one wave each): ratio (:710), adaptive keys in place (:711), high-byte histogram ----
+#pragma unroll 1
+  for (int h = wave; h < H; h += TK_WAVES) {
+    uint16_t* v = keys + (size_t)h * Lpad;
+    float ratio = 1.0f;
+    if (p.normalize) {
+      double st = 0.0;
+      for (int i = lane; i < p.base; i += 64) st += (double)Elem<T>::to_f32(v[i]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) st += __shfl_xor(st, o, 64);
+      const double a = s_rs[h];
+      const float tq = Elem<T>::to_f32(Elem<T>::from_f32((float)st));   // .sum() result in model dtype (:710)
+      const float aq = Elem<T>::to_f32(Elem<T>::from_f32((float)a));
+      ratio = Elem<T>::to_f32(Elem<T>::from_f32(tq / aq));              // model-dtype division (:710)
+    }
+    for (int i = lane; i < M; i += 64) {
+      const uint32_t key = adaptive_key<T>(v, i, ratio, p.normalize);
+      v[i] = (uint16_t)key;
+      atomicAdd(&X1[(key >> 8) * 32 + cslot], inc);
+    }
+  }
+  __syncthreads();
+  const uint32_t total = (uint32_t)((int64_t)H * p.base);            // <= H * M <= 47 104
+  select_bin(X1, hist, total, &misc[0], &misc[1], tid);
+  __syncthreads();
+  const uint32_t b1 = (uint32_t)misc[0];
+  const int above1 = misc[1];
+#pragma unroll 1
+  for (int h = wave; h < H; h += TK_WAVES) {
+    const uint16_t* v = keys + (size_t)h * Lpad;
+    for (int i = lane; i < M; i += 64) {
+      const uint32_t key = v[i];
+      if ((key >> 8) == b1) atomicAdd(&X2[(key & 255u) * 32 + cslot], inc);
+    }
+  }
+  __syncthreads();
+  select_bin(X2, hist, total - (uint32_t)above1, &misc[2], &misc[3], tid);
+  __syncthreads();
+  const uint32_t Tk = (b1 << 8) | (uint32_t)misc[2];
+  // ---- per head: entries above / at the threshold ----
+#pragma unroll 1
+  for (int h = wave; h < H; h += TK_WAVES) {
+    const uint16_t* v = keys + (size_t)h * Lpad;
+    uint32_t cg = 0, ce = 0;
+    for (int i = lane; i < M; i += 64) {
+      const uint32_t key = v[i];
+      cg += key > Tk;
+      ce += key == Tk;
+    }
+    const uint32_t packed = wave_sum_u32((ce << 16) | cg);             // <= 47 104 entries in total: no carry between the halves
+    if (lane == 0) { s_gt[h] = (int)(packed & 0xffffu); s_eq[h] = (int)(packed >> 16); }
+  }
+  __syncthreads();
+  const int gt = tid < H ? s_gt[tid] : 0, eq = tid < H ? s_eq[tid] : 0;
+  ada_finish<TK_WAVES>(p, gt, eq, p.one_minus_floor, p.window, p.head_lens_out, p.cu_klen_out, p.cu_headlens_out, s_red, s_scan);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -492,8 +622,8 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st) {
     return hipGetLastError();
   }
   if (lds > 48 * 1024) {                // the list kernels stage a whole list in LDS (the un-sorted kernels above use static LDS only)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = dyn_lds(reinterpret_cast<const void*>(k_stats), lds);
+    if (e == hipSuccess) e = dyn_lds(reinterpret_cast<const void*>(k_lo), lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_stats, dim3(p.H), dim3(256), lds, st, p, ws);
@@ -501,6 +631,22 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st) {
   hipLaunchKernelGGL(k_lo, dim3(p.H), dim3(256), lds, st, p, ws);
   hipLaunchKernelGGL(ada_final_kernel, dim3(1), dim3(256), 0, st, p, ws, omf, p.window, p.head_lens_out, p.cu_klen_out,
                      p.cu_headlens_out);
+  return hipGetLastError();
+}
+
+bool ada_fused_fits(int H, int M) {
+  const int64_t lpad = ((int64_t)M + 7) & ~(int64_t)7;
+  return H >= 1 && H <= 256 && M >= 1 && (int64_t)H * lpad <= ADA_FUSED_MAX_KEYS;
+}
+
+hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, int Lpad, const double* rowsum, hipStream_t st) {
+  auto fn = dtype == 0 ? ada_fused_kernel<BF16> : ada_fused_kernel<F16>;
+  const size_t lds = (((size_t)p.H * Lpad * 2 + 15) & ~(size_t)15) + (size_t)2 * TK_CNT_WORDS * 4;
+  if (lds > 48 * 1024) {
+    hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(1), dim3(TK_THREADS), lds, st, p, static_cast<const uint16_t*>(list), Lpad, rowsum);
   return hipGetLastError();
 }
 

@@ -42,6 +42,8 @@ constexpr int logits_ablate() { return 0; }   // the release library never reads
 
 // small-k selection algorithm of topk_kernel (identical results): 1 = one-level histogram + bucket counting sort
 int topk_algo() { static int t = env_int("PKV_TOPK_ALGO", 1); return t; }
+int topk_cmax() { static int t = env_int("PKV_TOPK_CMAX", 1); return t; }     // chunk maxima from finalize_kernel feed the top-k prefilter
+int ada_fused() { static int t = env_int("PKV_ADA_FUSED", 1); return t; }     // 0: the three-launch budget step of round 4 (A/B runs)
 // gather shape (both settings give identical results; defaults are the measured best, env vars exist for A/B runs)
 int gather_rpt() { static int t = env_int("PKV_GATHER_RPT", 0); return t; }   // 0 = by size (launch_gather)
 int gather_xcd() { static int t = env_int("PKV_GATHER_XCD", 0); return t; }
@@ -315,9 +317,11 @@ size_t topk_tmp_bytes(int rows, int L, int k) {
 
 int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t stride, const int32_t* kpr,
             int32_t* idx, int64_t idx_stride, hipStream_t st, const void* cmax = nullptr, int64_t cmax_stride = 0,
-            void* tmp = nullptr, size_t tmp_bytes = 0) {
+            void* tmp = nullptr, size_t tmp_bytes = 0, void* list_out = nullptr, int64_t list_stride = 0, double* rowsum_out = nullptr) {
   if (L < 1 || k < 1 || k > L || rows < 1) return PKV_ERR_SHAPE;
   TopkParams tp;
+  tp.list_out = list_out; tp.list_stride = list_stride; tp.rowsum_out = rowsum_out;    // Ada-SnapKV hand-over (single-workgroup rows only)
+  if (list_out && (dtype == PKV_F32 || !topk_fits(L, k))) return PKV_ERR_UNSUPPORTED;
   tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
   tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace; tp.wgtrace = g_wg_trace; tp.cmax = cmax; tp.cmax_stride = cmax_stride;
   tp.nseg = 1; tp.seg_len = 0; tp.algo = topk_algo();
@@ -395,7 +399,7 @@ int compress_common(bool h2o, const pkv_desc* d, const void* q, const void* k, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* w = static_cast<char*>(ws);
   void* scores = w + L.off_scores;
-  const bool cm = !h2o && d->dtype != PKV_F32 && env_int("PKV_TOPK_CMAX", 1) != 0;   // chunk maxima feed the top-k prefilter
+  const bool cm = !h2o && d->dtype != PKV_F32 && topk_cmax() != 0;   // chunk maxima feed the top-k prefilter
   rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
   int32_t* idx = idx_out ? idx_out : reinterpret_cast<int32_t*>(w + L.off_idx);
@@ -538,7 +542,7 @@ int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t h2o, int
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* w = static_cast<char*>(ws);
   void* scores = w + L.off_scores;
-  const bool cm = !h2o && d->dtype != PKV_F32 && env_int("PKV_TOPK_CMAX", 1) != 0;
+  const bool cm = !h2o && d->dtype != PKV_F32 && topk_cmax() != 0;
   rc = h2o ? do_score_h2o(d, q, k, scores, L.Lp, w, L, st) : do_score_window(d, q, k, scores, L.Lp, w, L, st, cm);
   if (rc) return rc;
   rc = do_topk(d->dtype, d->B * d->H, d->S - d->window, d->topk, scores, L.Lp, nullptr, idx_out, d->topk, st,
@@ -736,11 +740,16 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* w = static_cast<char*>(ws);
   void* scores = w + W.off_scores;
-  const bool cm = env_int("PKV_TOPK_CMAX", 1) != 0;
+  const bool cm = topk_cmax() != 0;
   rc = do_score_window(d, q, k, scores, W.Lp, w, W, st, cm);
   if (rc) return rc;
+  // Round 5: when the lists of all heads fit one workgroup's LDS the selection itself hands the budget step what it needs
+  // (every head's descending list of raw scores + the row sums) and the budgets are ONE single-workgroup launch
+  const int Lpad = (M + 7) & ~7;
+  const bool fused = !given_capacity && ada_fused_fits(H, M) && topk_fits(L, M) && ada_fused() != 0;
+  double* rowsum = reinterpret_cast<double*>(w + W.off_ada + 1024);           // [H][16] doubles inside the (unused) count tables
   rc = do_topk(d->dtype, H, L, M, scores, W.Lp, nullptr, top_idx, M, st, cm ? w + W.off_cmax : nullptr, W.Lp / 8,
-               w + W.off_tk, W.tk_bytes);
+               w + W.off_tk, W.tk_bytes, fused ? w + W.off_ada_list : nullptr, Lpad, fused ? rowsum : nullptr);
   if (rc) return rc;
   if (given_capacity) {                                    // HeadKV: capacities come from the host (:855); metadata only
     hipError_t e = launch_ada_metadata(H, d->window, given_capacity, head_lens, cu_klen, st, cu_headlens);
@@ -756,7 +765,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.adaptive_out = nullptr;
   bp.short_list = M < std::min<int64_t>(L, (int64_t)H * base_capacity) ? 1 : 0;
   ProfScope ps(PKV_K_BUDGET, st);
-  hipError_t e = launch_budget(d->dtype, bp, st);
+  hipError_t e = fused ? launch_ada_fused(d->dtype, bp, w + W.off_ada_list, Lpad, rowsum, st) : launch_budget(d->dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }
 

@@ -76,6 +76,12 @@ template <typename T> __device__ __forceinline__ uint32_t order_key(uint16_t h) 
   return k > 0xffffu ? 0xffffu : k;
 }
 
+// inverse of order_key for finite scores and +-inf (NaNs were collapsed onto the top key): the score's own bit pattern
+template <typename T> __device__ __forceinline__ uint16_t key_to_raw(uint32_t key) {
+  const uint32_t k = key - KeyBias<T>::v;
+  return (k & 0x8000u) ? (uint16_t)(k ^ 0x8000u) : (uint16_t)(~k);
+}
+
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
 

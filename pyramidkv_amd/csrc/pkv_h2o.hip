@@ -483,8 +483,7 @@ hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
   do {                                                                                                                \
     const size_t lds_ = (size_t)2 * HT * 4 * KS * 16;                                                                 \
     if (lds_ >= 64 * 1024) {                                                                                          \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(h2o_stats_kernel<TT, KS>),                    \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                    \
+      hipError_t e_ = dyn_lds(reinterpret_cast<const void*>(h2o_stats_kernel<TT, KS>), lds_);                    \
       if (e_ != hipSuccess) return e_;                                                                                \
     }                                                                                                                 \
     hipLaunchKernelGGL((h2o_stats_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                     \
@@ -503,8 +502,7 @@ hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st) {
   do {                                                                                                                \
     const size_t lds_ = (size_t)2 * HT * 4 * KS * 16 + 2 * HT * 4;                                                    \
     if (lds_ >= 64 * 1024) {                                                                                          \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(h2o_colsum_kernel<TT, KS>),                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                    \
+      hipError_t e_ = dyn_lds(reinterpret_cast<const void*>(h2o_colsum_kernel<TT, KS>), lds_);                    \
       if (e_ != hipSuccess) return e_;                                                                                \
     }                                                                                                                 \
     hipLaunchKernelGGL((h2o_colsum_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                    \

@@ -24,6 +24,25 @@ extern thread_local KernelEvents* g_kev;
     }                                                                                                               \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a (kernel, device) pair needs MORE dynamic LDS than it was last
+// granted - not on every launch (one runtime call per update_kv saved for top-k at S >= 16k; bench.py `host_us`).
+inline hipError_t dyn_lds(const void* fn, size_t bytes) {
+  struct Rec { const void* fn; int dev; size_t have; };
+  static thread_local Rec recs[48];
+  static thread_local int nrec = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Rec* hit = nullptr;
+  for (int i = 0; i < nrec; ++i)
+    if (recs[i].fn == fn && recs[i].dev == dev) { hit = &recs[i]; break; }
+  if (hit && hit->have >= bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  if (hit) hit->have = bytes;
+  else if (nrec < 48) recs[nrec++] = {fn, dev, bytes};
+  return hipSuccess;
+}
+
 // Measurement hooks (phase stamps, per-workgroup wall clocks, ablations that produce WRONG results) exist only in the
 // -DPKV_DEBUG build (make debug -> libpkv_debug.so, loaded by tools/ through PKV_LIB); in the release library the
 // accessors below are compile-time constants, so the hot loops carry no trace/ablation branches at all.
@@ -89,6 +108,12 @@ struct TopkParams {
   int algo;              // small-k fast path: 1 = one-level histogram + bucket counting sort, 0 = two-level select + radix ordering
   int nseg, seg_len;     // long rows: workgroup r handles segment r % nseg (seg_len keys) of row r / nseg and writes
                          // row-global indices to idx_out row r; L stays the full row length.  nseg <= 1: off
+  // Ada-SnapKV (round 5): the selection also hands over what the budget step needs of the row, so that no kernel has to
+  // look the winners' scores up again or re-read the row: the winners' RAW scores in output order (the head's descending
+  // list, :706) and the sum over ALL scores of the row (:710) as 16 per-wave partial sums (added in a fixed order later).
+  void* list_out;        // [rows][list_stride] model dtype, or null
+  int64_t list_stride;
+  double* rowsum_out;    // [rows][16], or null
 };
 
 struct SortParams {
@@ -207,6 +232,10 @@ hipError_t launch_aten_small_order(int dtype, int rows, int k, const void* score
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);
 hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
+// Ada-SnapKV budgets + metadata in ONE single-workgroup launch from the lists / row sums topk_kernel left behind (p.L entries
+// per head at list[h * Lpad]); ada_fused_fits() = the lists of all heads fit one workgroup's LDS next to the counters
+bool ada_fused_fits(int H, int M);
+hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, int Lpad, const double* rowsum, hipStream_t st);
 hipError_t launch_ada_final(const BudgetParams& p, int32_t* cum_hi, int32_t* cum_lo, const int32_t* above_hi, hipStream_t st);
 hipError_t launch_budget_f32(const BudgetParams& p, hipStream_t st);      // fp32 score rows (pkv_f32.hip), ws: 1024 + 4*H*256*4 + 4*H*4 bytes
 int budget_f32_max_row();

@@ -679,8 +679,7 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
 #define PKV_LAUNCH(TT, KPW, NT, KS)                                                                                     \
   do {                                                                                                                 \
     if (lds > 64 * 1024) {  /* wide GQA groups x wide windows: opt in to more than 64 KB of dynamic LDS */           \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(logits_kernel<TT, KPW, NT, KS>),              \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+      hipError_t e_ = dyn_lds(reinterpret_cast<const void*>(logits_kernel<TT, KPW, NT, KS>), lds);                      \
       if (e_ != hipSuccess) return e_;                                                                                \
     }                                                                                                                  \
     PKV_KLAUNCH((logits_kernel<TT, KPW, NT, KS>), grid, dim3(256), lds, st, p);                                       \

@@ -106,7 +106,11 @@ __device__ __forceinline__ void radix_pass(const uint32_t* src, uint32_t* dst, u
   __syncthreads();
 }
 
-template <typename T>
+// ADA (round 5, pkv_ada_select): the launch also emits, per row, the winners' raw scores in output order (p.list_out) and 16
+// per-wave partial sums over ALL scores of the row (p.rowsum_out) - what Ada-SnapKV's budget step (:709-719) needs of the
+// row - so that no later kernel looks the winners up again or re-reads the 2 MB of score rows.  A template parameter: the
+// plain selection keeps its register budget (120 VGPRs at 4 waves per SIMD).
+template <typename T, bool ADA>
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -138,6 +142,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   const bool dual = p.dual != 0;
 
   const uint16_t* src = reinterpret_cast<const uint16_t*>(p.scores) + (int64_t)row * p.scores_stride + seg_off;
+  int32_t* const orow = p.idx_out + (int64_t)vrow * p.idx_stride;
+  uint16_t* const lrow = ADA ? reinterpret_cast<uint16_t*>(p.list_out) + (int64_t)vrow * p.list_stride : nullptr;
+  // output position `pos` <- the winner with composite key<<16 | (0xffff - index)
+  auto emit = [&](int pos, uint32_t comp) {
+    orow[pos] = seg_off + (int32_t)(0xffffu - (comp & 0xffffu));
+    if (ADA) lrow[pos] = key_to_raw<T>(comp >> 16);
+  };
   const bool vec_ok = ((p.scores_stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
   const uint32_t inc = lane < 32 ? 1u : 65536u;
   const int cslot = lane & 31;
@@ -192,6 +203,22 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
   __syncthreads();
   if (PKV_TRACE(p) && tid == 0 && row == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PKV_TRACE(p)[7] = (unsigned long long)clock64(); }
+  if (ADA) {
+    // sum over all scores of the row (:710 `attn_score.sum(dim=-1)`), fp64 like ada_stats_kernel: this wave's share goes out
+    // as one partial, the 16 partials are added in wave order by the budget kernel (a fixed order: run-to-run identical)
+    double sa = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < niter) {
+        const int base = wave * Lw + j * 512 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (base + e < L) sa += (double)Elem<T>::to_f32(raw[j].h[e]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64);
+    if (lane == 0) p.rowsum_out[(int64_t)vrow * TK_WAVES + wave] = sa;
+  }
   U4 kreg[8];     // this lane's ordered keys (niter chunks of 8), kept in registers for every later pass
   auto transform_all = [&]() {
 #pragma unroll
@@ -375,7 +402,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
           const uint32_t st = d ? HB[d - 1] : 0u, en = HB[d];
           uint32_t rank = st;
           for (uint32_t jj = st; jj < en; ++jj) rank += tmpl[jj] > mine;
-          if (rank < (uint32_t)k) p.idx_out[(int64_t)vrow * p.idx_stride + rank] = seg_off + (int32_t)(0xffffu - (mine & 0xffffu));
+          if (rank < (uint32_t)k) emit((int)rank, mine);
         }
         PKV_STAMP(6);
         if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
@@ -489,8 +516,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         for (int q = 0; q < 8; ++q) rank += (a[q].x > mine) + (a[q].y > mine) + (a[q].z > mine) + (a[q].w > mine);
       }
       for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
-      if (g == 0 && ci < n && rank < k)
-        p.idx_out[(int64_t)vrow * p.idx_stride + rank] = seg_off + (int32_t)(0xffffu - (mine & 0xffffu));
+      if (g == 0 && ci < n && rank < k) emit(rank, mine);
     };
     if (C <= TK_FAST_C || (C <= TK_MID_C && dual)) {
       uint32_t* cand = X;                       // the stage-1 counters in X are no longer needed
@@ -526,8 +552,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         radix_pass(cand, tmp, table, hist, (int)C, ept, 0, tid);
         radix_pass(tmp, cand, table, hist, (int)C, ept, 1, tid);
         PKV_STAMP(5);
-        for (int i = tid; i < k; i += TK_THREADS)
-          p.idx_out[(int64_t)vrow * p.idx_stride + i] = seg_off + (int32_t)(0xffffu - (cand[i] & 0xffffu));
+        for (int i = tid; i < k; i += TK_THREADS) emit(i, cand[i]);
       }
       PKV_STAMP(6);
       if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
@@ -651,7 +676,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   __syncthreads();
   PKV_STAMP(5);
 
-  int32_t* out = p.idx_out + (int64_t)vrow * p.idx_stride;
   if (k <= TK_RANK_MAX) {
     // rank by counting: composites are unique, so ranks form a permutation of 0..k-1
     if (tid < k) {
@@ -664,7 +688,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
                 (a1.z > mine) + (a1.w > mine) + (a2.x > mine) + (a2.y > mine) + (a2.z > mine) + (a2.w > mine) +
                 (a3.x > mine) + (a3.y > mine) + (a3.z > mine) + (a3.w > mine);
       }
-      out[rank] = seg_off + (int32_t)(0xffffu - (mine & 0xffffu));
+      emit(rank, mine);
     }
   } else if (k <= TK_RADIX_MAX && dual) {
     // the compacted list is index-ordered within equal keys, so a STABLE sort by key alone gives the
@@ -674,7 +698,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     const int ept = (k + TK_THREADS - 1) / TK_THREADS;
     radix_pass(sel, sel2, table, hist, k, ept, 0, tid);
     radix_pass(sel2, sel, table, hist, k, ept, 1, tid);
-    for (int i = tid; i < k; i += TK_THREADS) out[i] = seg_off + (int32_t)(0xffffu - (sel[i] & 0xffffu));
+    for (int i = tid; i < k; i += TK_THREADS) emit(i, sel[i]);
   } else {
     // bitonic network, descending (kpad is a power of two here)
     int kp2 = 1;
@@ -693,7 +717,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         __syncthreads();
       }
     }
-    for (int i = tid; i < k; i += TK_THREADS) out[i] = seg_off + (int32_t)(0xffffu - (sel[i] & 0xffffu));
+    for (int i = tid; i < k; i += TK_THREADS) emit(i, sel[i]);
   }
   PKV_STAMP(6);
   if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
@@ -815,9 +839,10 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
 }
 
 hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st) {
-  auto fn = dtype == 0 ? topk_kernel<BF16> : topk_kernel<F16>;
+  const bool ada = p.list_out != nullptr && p.rowsum_out != nullptr;
+  auto fn = dtype == 0 ? (ada ? topk_kernel<BF16, true> : topk_kernel<BF16, false>) : (ada ? topk_kernel<F16, true> : topk_kernel<F16, false>);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
     if (e != hipSuccess) return e;
   }
   PKV_KLAUNCH(fn, dim3(rows), dim3(TK_THREADS), lds, st, p);
@@ -867,7 +892,7 @@ hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_
   auto fn = dtype == 0 ? sort_rows_kernel<BF16> : sort_rows_kernel<F16>;
   const size_t lds = (size_t)p.n * 4 + (size_t)TK_WAVES * 256 * 4 + 256 * 4;     // 2 x 16-bit per element + tables
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(rows), dim3(TK_THREADS), lds, st, p);

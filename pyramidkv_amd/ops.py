@@ -280,6 +280,137 @@ def compress(q, k, v, window: int, topk_k: int, pooling, kernel_size: int, scale
     return (ko, vo, idx) if return_indices else (ko, vo)
 
 
+# ---- prepared calls (round 5): everything of one update_kv that does not change from call to call ----------------------
+# At S <= 8192 one dense update_kv is bound by the HOST's time to issue it (bench.py `sweep[].host_us`).  A cluster therefore
+# keeps, per (shapes, strides, dtype, device, budget, knobs), the filled descriptor, its byref object, the scratch size and the
+# bound entry point; a call is then: one signature comparison, the raw current stream, two torch.empty, five data_ptr() and
+# ONE foreign call.  Anything unusual (operands that need a copy, budgets beyond one top-k workgroup, another current
+# device) is not prepared and takes the general path above.
+def _raw_stream(dev_index: int) -> int:
+    return torch._C._cuda_getCurrentRawStream(dev_index)
+
+
+class PreparedCompress:
+    """pkv_compress / pkv_compress_h2o for fixed shapes: built by ``prepare_compress`` from the tensors of a first call."""
+    __slots__ = ("qs", "ks", "vs", "qst", "kst", "vst", "dtype", "device", "dev_index", "desc", "dref", "nb", "fn", "what",
+                 "out_shape", "nidx", "knobs")
+
+    def hit(self, q, k, v) -> bool:
+        return (q.shape == self.qs and k.shape == self.ks and v.shape == self.vs and q.stride() == self.qst
+                and k.stride() == self.kst and v.stride() == self.vst and q.dtype is self.dtype and k.dtype is self.dtype
+                and v.dtype is self.dtype and q.device == self.device
+                and self.knobs == (_cfg.scale_mode, _cfg.tie_order, _cfg.gqa_dedup)
+                and torch._C._cuda_getDevice() == self.dev_index)
+
+    def run(self, q, k, v, idx_out=None):
+        qp, kp, vp = q.data_ptr(), k.data_ptr(), v.data_ptr()
+        if (qp | kp | vp) & 15:
+            return None                                   # a view that starts off a 16-byte boundary: the general path copies it
+        if idx_out is not None:
+            if idx_out.dtype != torch.int32 or not idx_out.is_contiguous() or idx_out.numel() != self.nidx:
+                raise ValueError("idx_out must be a contiguous int32 tensor of B*H*k elements")
+            ip = idx_out.data_ptr()
+        else:
+            ip = None
+        st = _raw_stream(self.dev_index)
+        ws = _WS.get((self.dev_index, st))
+        if ws is None or ws.numel() < self.nb:
+            ws = _workspace_and_stream(self.nb, self.device)[0]
+        ko = torch.empty(self.out_shape, dtype=self.dtype, device=self.device)
+        vo = torch.empty(self.out_shape, dtype=self.dtype, device=self.device)
+        rc = self.fn(self.dref, qp, kp, vp, ko.data_ptr(), vo.data_ptr(), ip, ws.data_ptr(), ws.numel(), st)
+        if rc:
+            N.check(rc, self.what)
+        return ko, vo
+
+
+def prepare_compress(q, k, v, window: int, topk_k: int, pooling, kernel_size: int, scale_mode: str, kv_group: int, h2o: bool,
+                     k_head_step: int = 1):
+    """-> PreparedCompress for exactly these operand layouts, or None when the call needs the general path.
+    ``k_head_step`` = g reads every g-th K/V head of expanded tensors (config.gqa_dedup: the view ``t[:, ::g]`` without
+    building it: same base pointer, head stride x g)."""
+    if not (q.is_cuda and k.is_cuda and v.is_cuda) or _needs_full_sort(q.shape[2] - window, topk_k, q.dtype):
+        return None
+    if any(_rowmajor(t) is not t for t in (q, k, v)) or q.device != k.device or q.device != v.device:
+        return None
+    pc = PreparedCompress()
+    pc.qs, pc.ks, pc.vs = q.shape, k.shape, v.shape
+    pc.qst, pc.kst, pc.vst = q.stride(), k.stride(), v.stride()
+    pc.dtype, pc.device = q.dtype, q.device
+    pc.dev_index = q.device.index if q.device.index is not None else torch.cuda.current_device()
+    kk, vv = (k, v) if k_head_step == 1 else (k[:, ::k_head_step], v[:, ::k_head_step])
+    pc.desc = make_desc(q, kk, vv, window, None if h2o else pooling, kernel_size, "sum", scale_mode, topk_k, kv_group)
+    pc.dref = N.C.byref(pc.desc)
+    pc.nb = N.lib.pkv_workspace_bytes(pc.desc)
+    pc.fn = N.lib.pkv_compress_h2o if h2o else N.lib.pkv_compress
+    pc.what = "pkv_compress_h2o" if h2o else "pkv_compress"
+    B, H, _, D = q.shape
+    pc.out_shape = (B, H, topk_k + window, D)
+    pc.nidx = B * H * topk_k
+    pc.knobs = (_cfg.scale_mode, _cfg.tie_order, _cfg.gqa_dedup)
+    return pc
+
+
+class PreparedAda:
+    """The two C calls of AdaKVCluster.update_kv on the list path (pkv_ada_select, then pkv_gather_flat on the device-resident
+    capacities) for fixed shapes and list length M.  ``run`` returns (head_lens, cu_klen, cu_headlens, K_flat, V_flat) with the
+    flat outputs sized by ``rows_bound``; the caller narrows them once the capacities are on the host."""
+    __slots__ = ("qs", "ks", "vs", "qst", "kst", "vst", "dtype", "device", "dev_index", "H", "M", "D", "dsel", "dsel_ref", "nb",
+                 "dgat", "dgat_ref", "rows_bound", "sizes", "base", "floor", "normalize", "knobs")
+
+    hit = PreparedCompress.hit
+
+    def run(self, q, k, v, mirror_ptr, seq):
+        qp, kp, vp = q.data_ptr(), k.data_ptr(), v.data_ptr()
+        if (qp | kp | vp) & 15:
+            return None
+        H, M = self.H, self.M
+        st = _raw_stream(self.dev_index)
+        ws = _WS.get((self.dev_index, st))
+        if ws is None or ws.numel() < self.nb:
+            ws = _workspace_and_stream(self.nb, self.device)[0]
+        buf = torch.empty(4 * H + 1 + H * M, dtype=torch.int32, device=self.device)     # cap | head_lens | cu_klen | cu_headlens | lists
+        _, head_lens, cu, cuh, _ = buf.split(self.sizes)
+        p0 = buf.data_ptr()
+        p_hl, p_cu, p_cuh, p_top = p0 + 4 * H, p0 + 8 * H, p0 + 4 * (3 * H + 1), p0 + 4 * (4 * H + 1)
+        rc = N.lib.pkv_ada_select(self.dsel_ref, qp, kp, self.base, self.floor, self.normalize, None, p_top, p0, p_hl, p_cu, p_cuh,
+                                  mirror_ptr, seq, ws.data_ptr(), ws.numel(), st)
+        if rc:
+            N.check(rc, "pkv_ada_select")
+        kf = torch.empty((self.rows_bound, self.D), dtype=self.dtype, device=self.device)
+        vf = torch.empty((self.rows_bound, self.D), dtype=self.dtype, device=self.device)
+        rc = N.lib.pkv_gather_flat(self.dgat_ref, kp, vp, p_top, M, p0, p_cu, kf.data_ptr(), vf.data_ptr(), self.rows_bound, st)
+        if rc:
+            N.check(rc, "pkv_gather_flat")
+        return head_lens, cu, cuh, kf, vf
+
+
+def prepare_ada(q, k, v, window: int, pooling, kernel_size: int, M: int, base_capacity: int, floor_ratio: float, normalize: bool,
+                scale_mode: str, kv_group: int, rows_bound: int):
+    """-> PreparedAda for exactly these operand layouts and list length, or None when the call needs the general path."""
+    if not (q.is_cuda and k.is_cuda and v.is_cuda) or q.dtype == torch.float32:
+        return None
+    if any(_rowmajor(t) is not t for t in (q, k, v)) or q.device != k.device or q.device != v.device:
+        return None
+    pa = PreparedAda()
+    pa.qs, pa.ks, pa.vs = q.shape, k.shape, v.shape
+    pa.qst, pa.kst, pa.vst = q.stride(), k.stride(), v.stride()
+    pa.dtype, pa.device = q.dtype, q.device
+    pa.dev_index = q.device.index if q.device.index is not None else torch.cuda.current_device()
+    H = q.shape[1]
+    pa.H, pa.M, pa.D = H, M, q.shape[3]
+    pa.dsel = make_desc(q, k, None, window, pooling, kernel_size, "mean", scale_mode, M, kv_group)
+    pa.dsel_ref = N.C.byref(pa.dsel)
+    pa.nb = N.lib.pkv_workspace_bytes(pa.dsel)
+    pa.dgat = make_desc(None, k, v, window, topk=M, kv_group=kv_group, num_heads=H)
+    pa.dgat_ref = N.C.byref(pa.dgat)
+    pa.rows_bound = rows_bound
+    pa.sizes = [H, H, H + 1, H, H * M]
+    pa.base, pa.floor, pa.normalize = int(base_capacity), float(floor_ratio), 1 if normalize else 0
+    pa.knobs = (_cfg.scale_mode, _cfg.tie_order, _cfg.gqa_dedup)
+    return pa
+
+
 def select(q, k, window: int, topk_k: int, pooling, kernel_size: int, scale_mode: str = "div", kv_group: int = 1,
            h2o: bool = False) -> torch.Tensor:
     """Score -> top-k only (the front half of ``compress``): int32 indices [B,H,k] in (value desc, index asc) order."""

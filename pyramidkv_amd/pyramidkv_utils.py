@@ -96,6 +96,13 @@ class _WindowPolicy:
     index_out = None
 
     def _compress(self, key_states, query_states, value_states, k, num_key_value_groups, h2o=False):
+        # fast path: the call prepared by an earlier update_kv of this cluster with the same layouts and knobs (ops.PreparedCompress)
+        sig = (k, h2o, self.window_size, self.pooling, self.kernel_size, getattr(self, "merge", None), num_key_value_groups)
+        prep = self.__dict__.get("_prep")
+        if prep is not None and prep[0] == sig and prep[1].hit(query_states, key_states, value_states):
+            out = prep[1].run(query_states, key_states, value_states, self.index_out)
+            if out is not None:
+                return out
         gu = _unexpanded_group(key_states, query_states)
         if k == 0 and getattr(self, "merge", None) is None:
             # a pyramid layer whose budget came out as 0 past tokens (tiny max_capacity_prompt - window_size, :205-215):
@@ -105,6 +112,7 @@ class _WindowPolicy:
         if k == 0:
             raise ValueError("merge='pivot' with a layer budget of 0 past tokens (max_capacity_prompt - window_size too small "
                              "for this layer count, :205-215) is not supported: there is no selected row to merge into")
+        k_in, v_in = key_states, value_states
         key_states, value_states, gu = _fit_group(key_states, value_states, gu, self.window_size)
         if getattr(self, "merge", None) is not None:                                 # :336-339: merge_kv instead of the gather
             g = gu if gu > 1 else _kv_group(num_key_value_groups, query_states.shape[1])
@@ -118,13 +126,19 @@ class _WindowPolicy:
                     raise ValueError("index_out must be a contiguous int32 tensor of B*H*k elements")
                 self.index_out.view_as(idx).copy_(idx)
             return ops.merge_compact(ks, vs, idx, self.window_size, kv_group=g)
+        step = 1
         if gu > 1:
-            return ops.compress(query_states, key_states, value_states, self.window_size, k, self.pooling,
-                                self.kernel_size, scale_mode=_cfg.scale_mode, kv_group=gu, h2o=h2o, idx_out=self.index_out)[:2]
-        g = _kv_group(num_key_value_groups, query_states.shape[1])
-        if g * self.window_size > _MAX_COLS:
-            g = 1
-        return ops.compress(query_states, _dedup_view(key_states, g), _dedup_view(value_states, g),
+            g = gu
+        else:
+            g = _kv_group(num_key_value_groups, query_states.shape[1])
+            if g * self.window_size > _MAX_COLS:
+                g = 1
+            step = g
+        if key_states is k_in and value_states is v_in:           # the operands go to the kernels as they are: remember the call
+            pc = ops.prepare_compress(query_states, key_states, value_states, self.window_size, k, self.pooling, self.kernel_size,
+                                      _cfg.scale_mode, g, h2o, k_head_step=step)
+            self._prep = (sig, pc) if pc is not None else None
+        return ops.compress(query_states, _dedup_view(key_states, step), _dedup_view(value_states, step),
                             self.window_size, k, self.pooling, self.kernel_size,
                             scale_mode=_cfg.scale_mode, kv_group=g, h2o=h2o, idx_out=self.index_out)[:2]
 
@@ -305,6 +319,7 @@ class _HostMirror:
     def __init__(self, H):
         self.t = torch.zeros(H + 1, dtype=torch.int32, pin_memory=True)
         self.np = self.t.numpy()                 # shares the pinned memory
+        self.ptr = self.t.data_ptr()
         self.H, self.seq = H, 0
 
     def next_seq(self):
@@ -446,27 +461,49 @@ class AdaKVCluster(_FlatPolicy):
                 mirror = getattr(self, "_mirror", None)
                 if mirror is None or mirror.H != num_heads:
                     mirror = self._mirror = _HostMirror(num_heads)
-            # Round 4: the lists start SHORT (config.ada_short_lists x base per head instead of M: the selection of 3840 entries
-            # per head is a third of this call at S = 32k, and no head of a real prompt comes near H x its base budget).  The
-            # budgets are exact unless the kernel reports a head whose list ran out (the threshold sits below the list's
-            # last entry); then the call is repeated with the full M.  The cluster - one per layer, :1049 - remembers twice the
-            # largest share it has seen.
+            # The lists start SHORT (round 4; round 5: config.ada_short_lists x base, at least 512 entries - what the top-k
+            # kernel's small-k path takes - instead of M: no head of a real prompt comes near H x its base budget).  The budgets
+            # are exact unless the kernel reports a head whose list ran out (the threshold sits below the list's last entry);
+            # then the call is repeated with the full M, and the cluster - one per layer, :1049 - remembers twice the largest
+            # share it has seen from then on.
             m_use = M
             if mirror is not None and _cfg.ada_short_lists > 0:
-                m_use = min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity))
+                m_use = min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity, 512))
             bound = num_heads * self.base_capacity + num_heads + num_heads * self.window_size
+            gq = _unexpanded_group(key_states, query_states)
+            sig = (m_use, self.window_size, self.pooling, self.kernel_size, self.base_capacity, self.floor_ratio, bool(self.normalize))
+            ran_out = False
+            if mirror is not None:
+                # fast path (round 5): both C calls prepared by an earlier update_kv with the same layouts (ops.PreparedAda)
+                prep = self.__dict__.get("_prep")
+                if prep is not None and prep[0] == sig and prep[1].hit(query_states, key_states, value_states):
+                    out = prep[1].run(query_states, key_states, value_states, mirror.ptr, mirror.next_seq())
+                    if out is not None:
+                        head_lens, cu, cuh, kf, vf = out
+                        caps = mirror.wait(key_states.device)
+                        if not (mirror.exhausted and m_use < M):
+                            klen_sum = sum(caps) + num_heads * self.window_size
+                            self._init_metadata(num_heads, head_lens, cu, klen_sum, max(caps) + self.window_size, key_states.device,
+                                                cu_headlens=cuh)
+                            self.head_capacity_last = caps
+                            return kf[:klen_sum], vf[:klen_sum]
+                        ran_out, m_use = True, M                     # a list ran out: repeated below with the full length
+                else:
+                    pa = ops.prepare_ada(query_states, key_states, value_states, self.window_size, self.pooling, self.kernel_size,
+                                         m_use, self.base_capacity, self.floor_ratio, bool(self.normalize), _cfg.scale_mode, gq, bound)
+                    self._prep = (sig, pa) if pa is not None else None
             while True:
                 sorted_idx, cap, head_lens, cu, cuh = ops.ada_select(
                     query_states, key_states, self.window_size, self.pooling, self.kernel_size, m_use, self.base_capacity,
-                    self.floor_ratio, bool(self.normalize), scale_mode=_cfg.scale_mode,
-                    kv_group=_unexpanded_group(key_states, query_states),               # :647-672, :706-719, :682-691
+                    self.floor_ratio, bool(self.normalize), scale_mode=_cfg.scale_mode, kv_group=gq,   # :647-672, :706-719, :682-691
                     host_mirror=mirror.t if mirror is not None else None, host_seq=mirror.next_seq() if mirror is not None else 0)
                 out = self._flat_from_capacity(key_states, value_states, sorted_idx, cap, num_heads, meta=(head_lens, cu, cuh),
                                                rows_bound=bound, mirror=mirror)
                 if m_use == M or not mirror.exhausted:
-                    self._list_len = max(getattr(self, "_list_len", 0), min(M, 2 * max(self.head_capacity_last)))
+                    if ran_out:      # remembered from now on: this layer's heads want longer lists than the default
+                        self._list_len = max(getattr(self, "_list_len", 0), min(M, 2 * max(self.head_capacity_last)))
                     return out
-                m_use = M
+                ran_out, m_use = True, M
         # H*base > 4096 (budget 2048: M is the whole row, a top-M list would be a full sort).  What :706-719 consume of the
         # order are selections and counts: the budgets come from histograms over the un-sorted rows (pkv_ada_budget_rows),
         # then every head's first cap_h entries of the canonical order from one top-k launch with per-head k.  Rows or
@@ -559,6 +596,18 @@ def _default(config, name, value):
         setattr(config, name, value)
 
 
+def _rebuilt(self, cluster):
+    """The reference rebuilds the dense clusters on every forward (:894,:918,:1003,:1025).  The prepared call of the cluster
+    being replaced (ops.PreparedCompress: descriptor + scratch size for the layouts it saw) moves to the new one - it is
+    keyed by every knob that could have changed, so a stale one is simply never hit."""
+    old = getattr(self, "kv_cluster", None)
+    if old is not None and type(old) is type(cluster):
+        prep = old.__dict__.get("_prep")
+        if prep is not None:
+            cluster._prep = prep
+    self.kv_cluster = cluster
+
+
 def init_pyramidkv(self, num_hidden_layers):
     """reference :880-902 (cluster rebuilt on every call, as there)."""
     if not hasattr(self, "kv_cluster"):
@@ -567,10 +616,10 @@ def init_pyramidkv(self, num_hidden_layers):
         _default(self.config, 'kernel_size', 5)
         _default(self.config, 'pooling', 'avgpool')
         _default(self.config, 'merge', None)
-    self.kv_cluster = PyramidKVCluster(
+    _rebuilt(self, PyramidKVCluster(
         num_hidden_layers=num_hidden_layers, layer_idx=self.layer_idx, window_size=self.config.window_size,
         max_capacity_prompt=self.config.max_capacity_prompt, kernel_size=self.config.kernel_size,
-        pooling=self.config.pooling, merge=self.config.merge)
+        pooling=self.config.pooling, merge=self.config.merge))
 
 
 def init_snapkv(self):
@@ -581,9 +630,9 @@ def init_snapkv(self):
         _default(self.config, 'kernel_size', 5)
         _default(self.config, 'pooling', 'avgpool')
         _default(self.config, 'merge', None)
-    self.kv_cluster = SnapKVCluster(
+    _rebuilt(self, SnapKVCluster(
         window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
-        kernel_size=self.config.kernel_size, pooling=self.config.pooling, merge=self.config.merge)
+        kernel_size=self.config.kernel_size, pooling=self.config.pooling, merge=self.config.merge))
 
 
 def init_H2O(self):
@@ -594,9 +643,9 @@ def init_H2O(self):
         _default(self.config, 'kernel_size', 5)
         _default(self.config, 'pooling', 'avgpool')
         _default(self.config, 'merge', None)
-    self.kv_cluster = H2OKVCluster(
+    _rebuilt(self, H2OKVCluster(
         window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
-        kernel_size=self.config.kernel_size, pooling=self.config.pooling, merge=self.config.merge)
+        kernel_size=self.config.kernel_size, pooling=self.config.pooling, merge=self.config.merge))
 
 
 def init_StreamingLLM(self):
@@ -607,9 +656,9 @@ def init_StreamingLLM(self):
         _default(self.config, 'kernel_size', 5)
         _default(self.config, 'pooling', 'avgpool')
         _default(self.config, 'merge', None)
-    self.kv_cluster = StreamingLLMKVCluster(
+    _rebuilt(self, StreamingLLMKVCluster(
         window_size=self.config.window_size, max_capacity_prompt=self.config.max_capacity_prompt,
-        kernel_size=self.config.kernel_size, pooling=self.config.pooling, merge=self.config.merge)
+        kernel_size=self.config.kernel_size, pooling=self.config.pooling, merge=self.config.merge))
 
 
 def init_adakv(self):

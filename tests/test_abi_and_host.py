@@ -451,17 +451,18 @@ def test_adakv_short_list_retry_logic_on_the_host(monkeypatch):
     assert m.wait("cpu") == [3, 9, 1, 7] and not m.exhausted
 
     calls = []
-    H, S, w, cap = 4, 1000, 8, 40                      # base 32: M = min(992, 128) = 128, first try 2 x 32 = 64 entries
+    H, S, w, cap = 4, 3000, 8, 308                     # base 300: M = min(2992, 1200) = 1200, first try max(2 x 300, 512) = 600 entries
     cl = U.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
     cl._mirror = m
+    run_out_below = [1000]
 
     def fake_select(q, k, window, pooling, ks, M, base, floor, norm, **kw):
         calls.append(M)
         return torch.zeros(H, M, dtype=torch.int32), torch.zeros(H, dtype=torch.int32), None, None, None
 
     def fake_flat(self, key_states, value_states, sorted_idx, cap_dev, num_heads, meta=None, rows_bound=None, mirror=None, caps_host=None):
-        mirror.exhausted = sorted_idx.shape[1] < 100          # the "kernel": lists shorter than 100 entries run out
-        self.head_capacity_last = [30, 90, 5, 3]
+        mirror.exhausted = sorted_idx.shape[1] < run_out_below[0]      # the "kernel": shorter lists run out
+        self.head_capacity_last = [30, 900, 5, 3]
         return "K", "V"
     monkeypatch.setattr(U.ops, "ada_select", fake_select)
     monkeypatch.setattr(U._FlatPolicy, "_flat_from_capacity", fake_flat)
@@ -471,12 +472,34 @@ def test_adakv_short_list_retry_logic_on_the_host(monkeypatch):
     monkeypatch.setattr(cfg, "ada_short_lists", 2)
     q = torch.zeros(1, H, S, 16, dtype=torch.bfloat16)
     assert cl.update_kv(q, q, q) == ("K", "V")
-    assert calls == [64, 128] and cl._list_len == 128          # ran out at 64 -> full length; remembers min(M, 2 x 90)
+    assert calls == [600, 1200] and cl._list_len == 1200       # ran out at 600 -> full length; remembers min(M, 2 x 900)
     calls.clear()
-    assert cl.update_kv(q, q, q) == ("K", "V") and calls == [128]
+    assert cl.update_kv(q, q, q) == ("K", "V") and calls == [1200]
+    # lists that never run out leave nothing remembered: the next call starts short again (round 5: a remembered length above
+    # 512 entries would push the selection off the top-k kernel's small-k path for no reason)
+    cl3 = U.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+    cl3._mirror = m
+    run_out_below[0] = 100
+    calls.clear()
+    cl3.update_kv(q, q, q)
+    cl3.update_kv(q, q, q)
+    assert calls == [600, 600] and not hasattr(cl3, "_list_len")
+    run_out_below[0] = 1000
+    # the floor of 512 entries: short lists of base budgets below 128 tokens still fill the small-k path
+    cl4 = U.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=8 + 100, floor=0.2, normalize=True)
+    cl4._mirror = m
+    calls.clear()
+    q8 = torch.zeros(1, 8, S, 16, dtype=torch.bfloat16)
+    monkeypatch.setattr(U, "_HostMirror", lambda H_: m)          # 8 heads would build a new (pinned) mirror
+    m.H = 8
+    run_out_below[0] = 0
+    cl4.update_kv(q8, q8, q8)
+    assert calls == [512]                                        # min(M = 800, max(2 x 100, 512))
+    m.H = 4
+    run_out_below[0] = 1000
     monkeypatch.setattr(cfg, "ada_short_lists", 0)
     cl2 = U.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
     cl2._mirror = m
     calls.clear()
     cl2.update_kv(q, q, q)
-    assert calls == [128]                                        # knob off: always the full length
+    assert calls == [1200]                                       # knob off: always the full length

@@ -742,7 +742,10 @@ def test_adakv_short_candidate_lists_are_exact_or_repeated(P, dt):
                 outs[factor] = (kf.cpu(), vf.cpu(), cl.head_lens.cpu().tolist(), cl.cu_klen.cpu().tolist(), cl.klen_sum, cl.max_seqlen_k)
                 if factor:
                     M = min(S - w, H * (cap - w))
-                    assert cl._list_len >= min(M, 2 * max(cl.head_capacity_last))
+                    if hasattr(cl, "_list_len"):             # set when a list ran out: the length this layer is served with from now on
+                        assert cl._list_len >= min(M, 2 * max(cl.head_capacity_last))
+                    else:
+                        assert max(cl.head_capacity_last) < max(factor * (cap - w), 512)
                     kf2, vf2 = cl.update_kv(kd, qd, vd)                  # second call of the same cluster: the remembered length
                     assert torch.equal(kf2.cpu(), outs[factor][0]) and torch.equal(vf2.cpu(), outs[factor][1])
             for factor in (1, 2, 8):
@@ -757,6 +760,49 @@ def test_adakv_short_candidate_lists_are_exact_or_repeated(P, dt):
                 assert max(outs[0][2]) > 4 * (cap - w)                               # the planted head really took several budgets
     finally:
         cfg.ada_short_lists = old
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_ada_select_one_launch_budgets_equal_the_three_launch_path_and_the_oracle(P, dt):
+    """Round 5: pkv_ada_select's budget step is ONE single-workgroup launch fed by the selection itself (top-k hands over every
+    head's descending list of raw scores and the row sums).  Capacities, metadata and the lists equal (a) the three-launch
+    path (pkv_topk + pkv_ada_budget_topm: ada_stats -> ada_lo -> ada_final on looked-up lists) and (b) the oracle's budget
+    arithmetic on the kernel's own scores - for head counts that do not fill the 16 waves evenly, full-length and short
+    lists, with and without normalisation, tie-saturated (lattice) scores included."""
+    rng = np.random.default_rng(5)
+    cases = [(1, 700, 8, 40, "gauss"), (5, 3000, 8, 72, "gauss"), (16, 6000, 8, 72, "lattice"), (17, 2500, 16, 56, "gauss"),
+             (32, 8192, 8, 128, "gauss"), (40, 4096, 8, 100, "lattice"), (32, 8192, 8, 128, "lattice"), (8, 1200, 4, 300, "gauss")]
+    for ci, (H, S, w, cap, kind) in enumerate(cases):
+        base = cap - w
+        L = S - w
+        q, k, v = make_qkv(1, H, S, 128, dt, kind, 300 + ci)
+        qd, kd = q.to(DEV), k.to(DEV)
+        pool, ks = ("maxpool", 7) if ci % 2 == 0 else ("avgpool", 5)
+        floor = float(rng.choice([0.0, 0.2, 0.5]))
+        sg = P.ops.score_window(qd, kd, w, pool, ks, "mean")[0]                       # [H, L] the kernel's own scores
+        for norm in (True, False):
+            Mfull = min(L, H * base)
+            for M in sorted({Mfull, min(Mfull, max(512, 2 * base))}):
+                if M > 4096:
+                    continue
+                mirror = torch.zeros(H + 1, dtype=torch.int32).pin_memory()
+                top, capd, hl, cu, cuh = P.ops.ada_select(qd, kd, w, pool, ks, M, base, floor, norm, host_mirror=mirror, host_seq=7)
+                torch.cuda.synchronize()
+                assert (int(mirror[H]) & 0x3fffffff) == 7
+                ran_out = bool(int(mirror[H]) & 0x40000000)
+                top3 = P.ops.topk(sg, M)
+                assert torch.equal(top, top3), (ci, norm, M)
+                if M == Mfull:
+                    cap3, hl3, cu3 = P.ops.ada_budget_topm(sg, top3, base, floor, norm, window=w)
+                    assert torch.equal(capd, cap3) and torch.equal(hl, hl3) and torch.equal(cu, cu3), (ci, norm, M)
+                    assert not ran_out
+                _, caps = O.adakv_head_capacity(sg.cpu()[None], base, floor, norm)
+                if not ran_out:
+                    assert capd.cpu().tolist() == caps[0].tolist() == mirror[:H].tolist(), (ci, norm, M)
+                    assert hl.cpu().tolist() == [c + w for c in caps[0].tolist()]
+                    assert cu.cpu().tolist() == [0] + np.cumsum(hl.cpu().numpy()).tolist() and cuh.cpu().tolist() == cu.cpu().tolist()[1:]
+                else:
+                    assert M < Mfull and max(caps[0].tolist()) >= 0
 
 
 def test_adakv_randomised_configs(P):
