@@ -35,7 +35,7 @@ __all__ = [
     "pyramid_budget", "window_logits", "window_scores", "h2o_scores", "h2o_scores_blocked",
     "pool_scores", "topk_canonical", "topk_reference", "gather_compact", "merge_kv", "merge_kv_explicit",
     "snapkv_update_kv", "pyramidkv_update_kv", "h2o_update_kv", "streamingllm_update_kv",
-    "adakv_update_kv", "headkv_update_kv", "AdaMeta", "equivalent_selection",
+    "adakv_update_kv", "headkv_update_kv", "AdaMeta", "equivalent_selection", "window_score_one_product_moved", "h2o_score_one_product_moved",
 ]
 
 
@@ -102,6 +102,61 @@ def window_scores(query_states, key_states, window_size: int, reduce: str = "sum
     return sl.sum(dim=-2) if reduce == "sum" else sl.mean(dim=-2)
 
 
+def _neighbour(x: torch.Tensor, step: int) -> torch.Tensor:
+    """The model-dtype value next above (step > 0) / below (step < 0) the finite 16-bit scalar tensor x."""
+    b = int(x.reshape(1).view(torch.int16).item()) & 0xffff
+    if b & 0x7fff == 0:                                   # +-0: the smallest value of the wanted sign
+        nb = 0x0001 if step > 0 else 0x8001
+    elif b < 0x8000:
+        nb = b + 1 if step > 0 else b - 1
+    else:
+        nb = b - 1 if step > 0 else b + 1
+    return torch.tensor([nb if nb < 0x8000 else nb - 0x10000], dtype=torch.int16).view(x.dtype)[0]
+
+
+def window_score_one_product_moved(query_states, key_states, window_size: int, b: int, h: int, j: int,
+                                   reduce: str = "sum", scale_mode: str = "div"):
+    """What ``window_scores`` (pyramidkv_utils.py:317-327 / :649-661) gives at position (b, h, j) when ONE of the w products
+    q_r . k_j of :317 - a model-dtype value, i.e. an fp32 accumulation rounded once - is rounded to its NEIGHBOUR instead:
+    the only freedom two correct implementations of :317 have (the accumulation order of the 128 terms; ATen's CPU kernel
+    and an MFMA disagree on it for products that sit at a rounding midpoint).  Returns (score as computed here without any
+    move, [(window_row, step, score), ...] for the 2w single moves).  16-bit tensors only."""
+    w = window_size
+    T = query_states.dtype
+    head_dim = query_states.shape[-1]
+    qw = query_states[b, h, -w:, :]
+    kk = key_states[b, h]
+    S = kk.shape[0]
+    P0 = torch.matmul(qw[None, None], kk.transpose(0, 1)[None, None])[0, 0]            # [w, S] model dtype (:317)
+    mask = _corner_mask(w, T, P0.device)
+
+    def column(prod):                                           # probabilities of column j for all w rows (model dtype)
+        A = _scale(prod[None, None], head_dim, scale_mode)[0, 0].clone()
+        A[-w:, -w:] += mask                                     # :322-324
+        return F.softmax(A, dim=-1, dtype=torch.float32).to(T)[:, j:j + 1]             # :326
+
+    def reduced(col):
+        return (col.sum(dim=-2) if reduce == "sum" else col.mean(dim=-2))[0]          # :327 / :661
+
+    base_col = column(P0)
+    moved = []
+    for r in range(w):
+        for step in (-1, 1):
+            P1 = P0[r:r + 1].clone()
+            P1[0, j] = _neighbour(P0[r, j], step)
+            A = _scale(P1[None, None], head_dim, scale_mode)[0, 0].clone()
+            if S - w <= j:
+                raise ValueError("position inside the observation window")
+            row_mask = torch.zeros(S, dtype=torch.float32)
+            row_mask[-w:] = mask[r]
+            A[0] += row_mask
+            pr = F.softmax(A, dim=-1, dtype=torch.float32).to(T)[0, j]
+            col = base_col.clone()
+            col[r, 0] = pr
+            moved.append((r, step, reduced(col)))
+    return reduced(base_col), moved
+
+
 def h2o_scores(query_states, key_states, window_size: int, scale_mode: str = "div") -> torch.Tensor:
     """pyramidkv_utils.py:544-554: ALL S query rows, full SxS (non-causal except the last w x w
     corner), fp32 softmax, column sum over all S rows of columns [0,S-w).  Materialises SxS:
@@ -114,6 +169,42 @@ def h2o_scores(query_states, key_states, window_size: int, scale_mode: str = "di
     attn[:, :, -w:, -w:] += mask[None, None, :, :]
     attn = F.softmax(attn, dim=-1, dtype=torch.float32).to(query_states.dtype)
     return attn[:, :, :, :-w].sum(dim=-2)
+
+
+def h2o_score_one_product_moved(query_states, key_states, window_size: int, b: int, h: int, j: int, top_rows: int = 8,
+                                scale_mode: str = "div"):
+    """``h2o_scores`` (pyramidkv_utils.py:544-554) at position (b, h, j) with ONE product q_i . k_j of :544 rounded to its
+    neighbour, for the ``top_rows`` query rows that contribute most to column j (a move in a row whose probability is far
+    below the column sum's last place cannot show).  Returns (score without a move, [(row, step, score), ...])."""
+    w = window_size
+    T = query_states.dtype
+    head_dim = query_states.shape[-1]
+    qh, kh = query_states[b, h], key_states[b, h]
+    S = kh.shape[0]
+    P0 = torch.matmul(qh[None, None], kh.transpose(0, 1)[None, None])[0, 0]             # [S, S] model dtype (:544)
+    mask = _corner_mask(w, T, P0.device)
+
+    def probs(prod, rows=None):
+        A = _scale(prod[None, None], head_dim, scale_mode)[0, 0].clone()
+        if rows is None:
+            A[-w:, -w:] += mask
+        else:
+            for t, r in enumerate(rows):
+                if r >= S - w:
+                    A[t, -w:] += mask[r - (S - w)]
+        return F.softmax(A, dim=-1, dtype=torch.float32).to(T)
+    col = probs(P0)[:, j].clone()                                                     # [S] model dtype
+    base = col[:, None].sum(dim=-2)[0]
+    order = torch.argsort(col.float(), descending=True)[:top_rows].tolist()
+    moved = []
+    for r in order:
+        for step in (-1, 1):
+            P1 = P0[r:r + 1].clone()
+            P1[0, j] = _neighbour(P0[r, j], step)
+            c2 = col.clone()
+            c2[r] = probs(P1, rows=[r])[0, j]
+            moved.append((r, step, c2[:, None].sum(dim=-2)[0]))
+    return base, moved
 
 
 def h2o_scores_blocked(query_states, key_states, window_size: int, block: int = 128,

@@ -385,6 +385,119 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, c
   ada_finish<TK_WAVES>(p, gt, eq, p.one_minus_floor, p.window, p.head_lens_out, p.cu_klen_out, p.cu_headlens_out, s_red, s_scan);
 }
 
+// The same step for the shapes the short candidate lists produce (H <= 16 * RH heads, lists of at most 64 * TM entries): every
+// lane keeps its entries - entries lane, lane + 64, ... of heads wave, wave + 16 - in REGISTERS from the one global load on
+// (no staging of the lists in LDS, no LDS round trip per entry and phase: a single workgroup runs 16 waves on one CU, where
+// every dependent LDS access costs ~100 cycles of wall time and the three phases below walked the lists three times).
+// LDS holds the two bank-spread counter arrays only.  12.7 -> see profiles/r05 (H = 32, lists of 512).
+template <typename T, int RH, int TM>
+__global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams p, const uint16_t* list, int Lpad, const double* rowsum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ada_smem[];
+  __shared__ __attribute__((aligned(16))) uint32_t hist[256];
+  __shared__ int misc[4];
+  __shared__ int s_gt[256], s_eq[256];
+  __shared__ double s_rs[256];
+  __shared__ int64_t s_red[TK_WAVES];
+  __shared__ int s_scan[TK_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, M = p.L;
+  uint32_t* X1 = reinterpret_cast<uint32_t*>(ada_smem);
+  uint32_t* X2 = X1 + TK_CNT_WORDS;
+  const uint32_t inc = lane < 32 ? 1u : 65536u;
+  const int cslot = lane & 31;
+  // one round trip: this lane's list entries and (thread h: head h) the 16 partial row sums
+  uint32_t key[RH][TM];
+#pragma unroll
+  for (int r = 0; r < RH; ++r) {
+    const int h = wave + r * TK_WAVES;
+    const uint16_t* v = list + (size_t)(h < H ? h : 0) * Lpad;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { const int i = lane + 64 * t; key[r][t] = v[i < M ? i : 0]; }
+  }
+  double2 rp[TK_WAVES / 2];
+  if (p.normalize && tid < H) {
+#pragma unroll
+    for (int j = 0; j < TK_WAVES / 2; ++j) rp[j] = reinterpret_cast<const double2*>(rowsum + (int64_t)tid * TK_WAVES)[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 2 * TK_CNT_WORDS / (4 * TK_THREADS); ++j)           // X1 and X2 are adjacent: 4 x 16 B per thread
+    reinterpret_cast<uint4*>(X1)[j * TK_THREADS + tid] = make_uint4(0, 0, 0, 0);
+  if (p.normalize && tid < H) {                                           // the 16 partials in wave order: a fixed order
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < TK_WAVES / 2; ++j) { a += rp[j].x; a += rp[j].y; }
+    s_rs[tid] = a;
+  }
+  __syncthreads();
+  // ---- ratio (:710), adaptive keys (:711), high-byte histogram ----
+  float ratio[RH];
+  if (p.normalize) {
+    double st[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      st[r] = 0.0;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) if (lane + 64 * t < p.base) st[r] += (double)Elem<T>::to_f32((uint16_t)key[r][t]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int r = 0; r < RH; ++r) st[r] += __shfl_xor(st[r], o, 64);     // the RH reductions run interleaved
+    }
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      const int h = wave + r * TK_WAVES;
+      const double a = s_rs[h < H ? h : 0];
+      const float tq = Elem<T>::to_f32(Elem<T>::from_f32((float)st[r]));   // .sum() result in model dtype (:710)
+      const float aq = Elem<T>::to_f32(Elem<T>::from_f32((float)a));
+      ratio[r] = Elem<T>::to_f32(Elem<T>::from_f32(tq / aq));              // model-dtype division (:710)
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RH; ++r) {
+    const bool hv = wave + r * TK_WAVES < H;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      uint16_t hraw = (uint16_t)key[r][t];
+      if (p.normalize) hraw = Elem<T>::from_f32(Elem<T>::to_f32(hraw) * ratio[r]);   // adaptive_attn_score * ratio_weight (:711)
+      const uint32_t k = (hv && lane + 64 * t < M) ? order_key<T>(hraw) : 0u;       // 0 = no entry (real keys are >= 1)
+      key[r][t] = k;
+      if (k) atomicAdd(&X1[(k >> 8) * 32 + cslot], inc);
+    }
+  }
+  __syncthreads();
+  const uint32_t total = (uint32_t)((int64_t)H * p.base);
+  select_bin(X1, hist, total, &misc[0], &misc[1], tid);
+  __syncthreads();
+  const uint32_t b1 = (uint32_t)misc[0];
+  const int above1 = misc[1];
+#pragma unroll
+  for (int r = 0; r < RH; ++r) {
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const uint32_t k = key[r][t];
+      if (k && (k >> 8) == b1) atomicAdd(&X2[(k & 255u) * 32 + cslot], inc);
+    }
+  }
+  __syncthreads();
+  select_bin(X2, hist, total - (uint32_t)above1, &misc[2], &misc[3], tid);
+  __syncthreads();
+  const uint32_t Tk = (b1 << 8) | (uint32_t)misc[2];
+  // ---- per head: entries above / at the threshold ----
+#pragma unroll
+  for (int r = 0; r < RH; ++r) {
+    uint32_t packed = 0;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { const uint32_t k = key[r][t]; packed += (k > Tk ? 1u : 0u) + (k == Tk ? 65536u : 0u); }
+    packed = wave_sum_u32(packed);
+    const int h = wave + r * TK_WAVES;
+    if (lane == 0 && h < H) { s_gt[h] = (int)(packed & 0xffffu); s_eq[h] = (int)(packed >> 16); }
+  }
+  __syncthreads();
+  const int gt = tid < H ? s_gt[tid] : 0, eq = tid < H ? s_eq[tid] : 0;
+  ada_finish<TK_WAVES>(p, gt, eq, p.one_minus_floor, p.window, p.head_lens_out, p.cu_klen_out, p.cu_headlens_out, s_red, s_scan);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Un-sorted variants (BudgetParams::unsorted): the same cum_hi / cum_lo tables straight from the score rows, by counting.
 // Used when H * base > 4096 (budget 2048: M = min(L, H * base) is the whole row and a top-M list is a full sort).
@@ -639,7 +752,22 @@ bool ada_fused_fits(int H, int M) {
   return H >= 1 && H <= 256 && M >= 1 && (int64_t)H * lpad <= ADA_FUSED_MAX_KEYS;
 }
 
+template <typename T, int RH>
+static hipError_t launch_ada_fused_reg(const BudgetParams& p, const uint16_t* list, int Lpad, const double* rowsum, hipStream_t st) {
+  auto fn = ada_fused_reg_kernel<T, RH, 8>;
+  const size_t lds = (size_t)2 * TK_CNT_WORDS * 4;
+  hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(1), dim3(TK_THREADS), lds, st, p, list, Lpad, rowsum);
+  return hipGetLastError();
+}
+
 hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, int Lpad, const double* rowsum, hipStream_t st) {
+  if (p.L <= 512 && p.H <= 32) {          // the short-list shapes: entries in registers (at most 2 heads x 8 entries per lane)
+    const uint16_t* l16 = static_cast<const uint16_t*>(list);
+    if (p.H <= 16) return dtype == 0 ? launch_ada_fused_reg<BF16, 1>(p, l16, Lpad, rowsum, st) : launch_ada_fused_reg<F16, 1>(p, l16, Lpad, rowsum, st);
+    return dtype == 0 ? launch_ada_fused_reg<BF16, 2>(p, l16, Lpad, rowsum, st) : launch_ada_fused_reg<F16, 2>(p, l16, Lpad, rowsum, st);
+  }
   auto fn = dtype == 0 ? ada_fused_kernel<BF16> : ada_fused_kernel<F16>;
   const size_t lds = (((size_t)p.H * Lpad * 2 + 15) & ~(size_t)15) + (size_t)2 * TK_CNT_WORDS * 4;
   if (lds > 48 * 1024) {

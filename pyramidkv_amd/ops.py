@@ -370,7 +370,6 @@ class PreparedAda:
         if ws is None or ws.numel() < self.nb:
             ws = _workspace_and_stream(self.nb, self.device)[0]
         buf = torch.empty(4 * H + 1 + H * M, dtype=torch.int32, device=self.device)     # cap | head_lens | cu_klen | cu_headlens | lists
-        _, head_lens, cu, cuh, _ = buf.split(self.sizes)
         p0 = buf.data_ptr()
         p_hl, p_cu, p_cuh, p_top = p0 + 4 * H, p0 + 8 * H, p0 + 4 * (3 * H + 1), p0 + 4 * (4 * H + 1)
         rc = N.lib.pkv_ada_select(self.dsel_ref, qp, kp, self.base, self.floor, self.normalize, None, p_top, p0, p_hl, p_cu, p_cuh,
@@ -382,6 +381,7 @@ class PreparedAda:
         rc = N.lib.pkv_gather_flat(self.dgat_ref, kp, vp, p_top, M, p0, p_cu, kf.data_ptr(), vf.data_ptr(), self.rows_bound, st)
         if rc:
             N.check(rc, "pkv_gather_flat")
+        _, head_lens, cu, cuh, _ = buf.split(self.sizes)          # views for the metadata attributes: after both calls are issued
         return head_lens, cu, cuh, kf, vf
 
 

@@ -441,7 +441,32 @@ class AdaKVCluster(_FlatPolicy):
         self.layer_idx = layer_idx
         self._init_state()
 
+    def _fast_sig(self):
+        return (self.window_size, self.pooling, self.kernel_size, self.base_capacity, self.floor_ratio, self.normalize,
+                _cfg.host_poll, _cfg.ada_short_lists, self.__dict__.get("_list_len", 0))
+
     def update_kv(self, key_states, query_states, value_states):
+        # fast path (round 5): the two C calls prepared by an earlier update_kv of this cluster with the same layouts, list length
+        # and knobs (ops.PreparedAda) - between the capacities arriving on the host and the first kernel of the NEXT call lies
+        # nothing but this check, one allocation and one foreign call (the host sync of the policy, :718, makes every
+        # microsecond of host work here a microsecond of idle GPU)
+        fast = self.__dict__.get("_fast")
+        if fast is not None and fast[0] == self._fast_sig() and fast[1].hit(query_states, key_states, value_states):
+            pa, mirror, m_use, M = fast[1], fast[2], fast[3], fast[4]
+            out = pa.run(query_states, key_states, value_states, mirror.ptr, mirror.next_seq())
+            if out is not None:
+                head_lens, cu, cuh, kf, vf = out
+                num_heads, w = pa.H, self.window_size
+                self._init_metadata(num_heads, head_lens, cu, 0, 0, pa.device, cu_headlens=cuh)    # everything but the two host ints
+                caps = mirror.wait(pa.device)
+                if not (mirror.exhausted and m_use < M):
+                    klen_sum = sum(caps) + num_heads * w
+                    self.klen_sum = klen_sum                                             # :685
+                    self.max_seqlen_k = max(caps) + w                                    # :686
+                    self.head_capacity_last = caps
+                    return kf[:klen_sum], vf[:klen_sum]
+                self._fast = None                                    # a list ran out: the general path repeats with the full length
+                self._force_full = True
         bsz, num_heads, q_len, head_dim = query_states.shape
         L = q_len - self.window_size
         if self.base_capacity > L:                                                   # :700
@@ -471,27 +496,9 @@ class AdaKVCluster(_FlatPolicy):
                 m_use = min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity, 512))
             bound = num_heads * self.base_capacity + num_heads + num_heads * self.window_size
             gq = _unexpanded_group(key_states, query_states)
-            sig = (m_use, self.window_size, self.pooling, self.kernel_size, self.base_capacity, self.floor_ratio, bool(self.normalize))
-            ran_out = False
-            if mirror is not None:
-                # fast path (round 5): both C calls prepared by an earlier update_kv with the same layouts (ops.PreparedAda)
-                prep = self.__dict__.get("_prep")
-                if prep is not None and prep[0] == sig and prep[1].hit(query_states, key_states, value_states):
-                    out = prep[1].run(query_states, key_states, value_states, mirror.ptr, mirror.next_seq())
-                    if out is not None:
-                        head_lens, cu, cuh, kf, vf = out
-                        caps = mirror.wait(key_states.device)
-                        if not (mirror.exhausted and m_use < M):
-                            klen_sum = sum(caps) + num_heads * self.window_size
-                            self._init_metadata(num_heads, head_lens, cu, klen_sum, max(caps) + self.window_size, key_states.device,
-                                                cu_headlens=cuh)
-                            self.head_capacity_last = caps
-                            return kf[:klen_sum], vf[:klen_sum]
-                        ran_out, m_use = True, M                     # a list ran out: repeated below with the full length
-                else:
-                    pa = ops.prepare_ada(query_states, key_states, value_states, self.window_size, self.pooling, self.kernel_size,
-                                         m_use, self.base_capacity, self.floor_ratio, bool(self.normalize), _cfg.scale_mode, gq, bound)
-                    self._prep = (sig, pa) if pa is not None else None
+            ran_out = self.__dict__.pop("_force_full", False)            # the fast path above saw a list run out
+            if ran_out:
+                m_use = M
             while True:
                 sorted_idx, cap, head_lens, cu, cuh = ops.ada_select(
                     query_states, key_states, self.window_size, self.pooling, self.kernel_size, m_use, self.base_capacity,
@@ -502,6 +509,12 @@ class AdaKVCluster(_FlatPolicy):
                 if m_use == M or not mirror.exhausted:
                     if ran_out:      # remembered from now on: this layer's heads want longer lists than the default
                         self._list_len = max(getattr(self, "_list_len", 0), min(M, 2 * max(self.head_capacity_last)))
+                    if mirror is not None:                           # the next call with these layouts takes the fast path above
+                        m_next = min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity, 512)) \
+                            if _cfg.ada_short_lists > 0 else M
+                        pa = ops.prepare_ada(query_states, key_states, value_states, self.window_size, self.pooling, self.kernel_size,
+                                             m_next, self.base_capacity, self.floor_ratio, bool(self.normalize), _cfg.scale_mode, gq, bound)
+                        self._fast = (self._fast_sig(), pa, mirror, m_next, M) if pa is not None else None
                     return out
                 ran_out, m_use = True, M
         # H*base > 4096 (budget 2048: M is the whole row, a top-M list would be a full sort).  What :706-719 consume of the

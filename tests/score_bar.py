@@ -1,0 +1,97 @@
+"""The floating-point bar of the score stage, stated as what is actually true (review of round 4, item 3).
+
+Two correct implementations of pyramidkv_utils.py:317 can disagree about ONE thing: the rounding of a product q.k that sits at a
+model-dtype rounding midpoint (fp32 accumulation order of the 128 terms: ATen's CPU kernel one way, the MFMA the other).  Such
+a logit moves its probability by |logit| units of the last place, so "every score within 1 ulp of the oracle" is true on most
+seeds and false on some.  The bar used by the GPU tests:
+
+  * every element within 1 ulp of the oracle, OR reproduced (to the last place, or within one) by the oracle re-run with ONE
+    product of that position rounded to its neighbour (oracle.window_score_one_product_moved);
+  * such elements are rare: at most max(2, 1e-4 x elements) per tensor;
+  * elements that differ at all: at most `frac_bar` of the tensor (the two sides evaluate exp / sums in different orders);
+  * pooling adds nothing: the kernel's pooled scores are the oracle's pooling of the kernel's own un-pooled scores (max: exact,
+    avg: within 1 ulp), and every pooled element beyond 1 ulp lies within kernel/2 of an explained un-pooled one.
+"""
+import numpy as np
+import torch
+
+from inputs import bits
+from oracle import pkv_oracle as O
+
+
+def ord16(t: torch.Tensor) -> np.ndarray:
+    b = bits(t).astype(np.int64)
+    return np.where(b & 0x8000, -(b & 0x7FFF), b)
+
+
+def _ord_scalar(x) -> int:
+    return int(ord16(x.reshape(1))[0])
+
+
+def explain_window_scores(q, kx, w, got_unpooled, want_unpooled, reduce="sum", scale_mode="div", limit=64):
+    """-> (number of elements beyond 1 ulp, how many of them one moved product reproduces exactly, ... within 1 ulp, positions)."""
+    d = np.abs(ord16(got_unpooled) - ord16(want_unpooled))
+    pos = np.argwhere(d > 1)
+    exact = near = 0
+    unexplained = []
+    for (b, h, j) in pos[:limit]:
+        g = _ord_scalar(got_unpooled[b, h, j])
+        _, moved = O.window_score_one_product_moved(q, kx, w, int(b), int(h), int(j), reduce, scale_mode)
+        dist = min(abs(_ord_scalar(m[2]) - g) for m in moved)
+        if dist == 0:
+            exact += 1
+        elif dist <= 1:
+            near += 1
+        else:
+            unexplained.append((int(b), int(h), int(j), int(d[b, h, j]), int(dist)))
+    return len(pos), exact, near, unexplained, pos
+
+
+def check_window_scores(q, kx, w, pool, ks, reduce, got_pooled, unpooled_fn, scale_mode="div", frac_bar=2e-3, what=""):
+    """Assert the bar above for window scores.  ``kx`` = K as the reference receives it (expanded), ``got_pooled`` = the kernel's
+    scores (CPU), ``unpooled_fn()`` -> the kernel's un-pooled scores of the same call (only evaluated when something is beyond
+    1 ulp).  Returns a small report dict."""
+    want_u = O.window_scores(q, kx, w, reduce, scale_mode)
+    want = O.pool_scores(want_u, pool, ks)
+    d = np.abs(ord16(got_pooled) - ord16(want))
+    frac, mx = float((d > 0).mean()), int(d.max())
+    rep = dict(mismatch_frac=frac, max_ulp=mx, beyond_1ulp=0, reproduced_exactly=0, reproduced_within_1ulp=0)
+    assert frac <= frac_bar, (what, frac, mx)
+    if mx <= 1:
+        return rep
+    got_u = unpooled_fn()
+    n, exact, near, unexplained, pos = explain_window_scores(q, kx, w, got_u, want_u, reduce, scale_mode)
+    rep.update(beyond_1ulp=n, reproduced_exactly=exact, reproduced_within_1ulp=near)
+    assert not unexplained, (what, "scores beyond 1 ulp that no single moved product explains", unexplained[:4])
+    assert n <= max(2, 1e-4 * got_u.numel()), (what, n, got_u.numel())
+    # pooling on top of the kernel's own un-pooled scores
+    repool = O.pool_scores(got_u, pool, ks)
+    dp = np.abs(ord16(got_pooled) - ord16(repool))
+    assert int(dp.max()) <= (0 if pool in (None, "none", "maxpool") else 1), (what, "pooling stage", int(dp.max()))
+    reach = (ks // 2) if pool not in (None, "none") else 0
+    marked = np.zeros(d.shape, dtype=bool)
+    for (b, h, j) in pos:
+        marked[b, h, max(0, j - reach):j + reach + 1] = True
+    assert not (d > 1)[~marked].any(), (what, "a pooled score beyond 1 ulp away from every explained un-pooled one")
+    return rep
+
+
+def check_h2o_scores(q, kx, w, got, frac_bar=1e-3, scale_mode="div", what=""):
+    """The same bar for H2O column sums (small S: the oracle materialises S x S)."""
+    want = O.h2o_scores(q, kx, w, scale_mode)
+    d = np.abs(ord16(got) - ord16(want))
+    frac, mx = float((d > 0).mean()), int(d.max())
+    rep = dict(mismatch_frac=frac, max_ulp=mx, beyond_1ulp=0, reproduced_exactly=0, reproduced_within_1ulp=0)
+    assert frac <= max(frac_bar, 8.0 / got.numel()), (what, frac, mx)
+    if mx <= 1:
+        return rep
+    pos = np.argwhere(d > 1)
+    assert len(pos) <= max(2, 1e-4 * got.numel()), (what, len(pos))
+    for (b, h, j) in pos:
+        g = _ord_scalar(got[b, h, j])
+        _, moved = O.h2o_score_one_product_moved(q, kx, w, int(b), int(h), int(j), 8, scale_mode)
+        dist = min(abs(_ord_scalar(m[2]) - g) for m in moved)
+        assert dist <= 1, (what, "H2O score beyond 1 ulp that no single moved product explains", (int(b), int(h), int(j), int(d[b, h, j]), dist))
+        rep["reproduced_exactly" if dist == 0 else "reproduced_within_1ulp"] += 1
+    rep["beyond_1ulp"] = len(pos)
+    return rep

@@ -17,6 +17,7 @@ import torch
 
 from inputs import make_qkv, bits
 from oracle import pkv_oracle as O
+from score_bar import check_window_scores
 from test_gpu_parity import DEV, ord16, score_diff, _report
 
 pytestmark = pytest.mark.gpu
@@ -141,6 +142,30 @@ def test_config3_h2o_32k_vs_oracle(P, dt):
         if cap == 128:
             assert bool(seq_h.all()), seq_h
         assert bool((kv_h | ~seq_h).all()), "same index sequence but different K/V bits"
+        # Why an order / set differs, per head and in the record (review of round 4): the two implementations' scores agree
+        # within `mx` units of the last place, so the kernel can rank a before b against the oracle only when the ORACLE's own
+        # scores of a and b lie within 2 * mx units - asserted for every adjacent pair of the kernel's order and for every
+        # token the kernel keeps that the oracle drops (against the oracle's k-th score).
+        wo = ord16(want)
+        heads = []
+        for b in range(B):
+            for h in range(H):
+                if bool(seq_h[b, h]):
+                    continue
+                mine, ref = ia[b, h].numpy(), ridx[b, h].numpy()
+                so_mine = wo[b, h][mine]
+                inv = int(max(0, (so_mine[1:] - so_mine[:-1]).max()))
+                kth = int(wo[b, h][ref[-1]])
+                extra = sorted(set(mine.tolist()) - set(ref.tolist()))
+                short = [int(kth - wo[b, h][t]) for t in extra]
+                first = int(np.argmax(mine != ref))
+                heads.append(dict(batch=b, head=h, positions_that_differ=int((mine != ref).sum()), first_differing_position=first,
+                                  largest_rise_of_the_oracle_scores_in_kernel_order_ulp=inv,
+                                  tokens_kept_here_not_by_the_oracle=len(extra), their_oracle_score_below_the_kth_ulp=short[:8],
+                                  oracle_score_band_of_the_last_64_kept_ulp=int(wo[b, h][ref[-64]] - kth) if len(ref) >= 64 else None))
+                assert inv <= 2 * max(1, mx), (cap, b, h, inv)
+                assert all(0 <= s_ <= 2 * max(1, mx) for s_ in short), (cap, b, h, short)
+        rep[f"cap{cap}"]["heads_in_another_order"] = heads
     _report(f"config3/h2o/S32768/B2H4/{dt}", rep)
 
 
@@ -510,9 +535,8 @@ def test_head_sizes_64_and_256_window_policies(P, D, dt):
     vd = v_un.to(DEV)
     for pool, ks in (("maxpool", 7), ("avgpool", 5)):
         sg = P.ops.score_window(qd, kd, w, pool, ks, kv_group=g)
-        so = O.pool_scores(O.window_scores(q, k_exp, w), pool, ks)
-        frac, mx = score_diff(sg.cpu(), so)
-        assert mx <= 1 and frac <= SCORE_FRAC, (D, dt, pool, frac, mx)
+        check_window_scores(q, k_exp, w, pool, ks, "sum", sg.cpu(), lambda: P.ops.score_window(qd, kd, w, None, 1, kv_group=g).cpu(),
+                            frac_bar=SCORE_FRAC, what=(D, dt, pool))
         kc, vc, idx = P.ops.compress(qd, kd, vd, w, k, pool, ks, kv_group=g, return_indices=True)
         want = O.topk_canonical(sg.cpu(), k)
         assert torch.equal(idx.cpu().long(), want)
@@ -608,10 +632,9 @@ def test_one_million_token_prompt(P):
     k = torch.randn(B, H, S, 128, generator=g).to(torch.bfloat16)
     v = torch.randn(B, H, S, 128, generator=g).to(torch.bfloat16)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    want = O.pool_scores(O.window_scores(q, k, w), "maxpool", 7)
     got = P.ops.score_window(qd, kd, w, "maxpool", 7).cpu()
-    frac, mx = score_diff(got, want)
-    assert mx <= 1 and frac <= SCORE_FRAC, (frac, mx)
+    rep1m = check_window_scores(q, k, w, "maxpool", 7, "sum", got, lambda: P.ops.score_window(qd, kd, w, None, 1).cpu(), frac_bar=SCORE_FRAC)
+    frac, mx = rep1m["mismatch_frac"], rep1m["max_ulp"]
     kc, vc, idx = P.ops.compress(qd, kd, vd, w, cap - w, "maxpool", 7, return_indices=True)
     idx = idx.cpu().long()
     assert torch.equal(idx, O.topk_canonical(got, cap - w))

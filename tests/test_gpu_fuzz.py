@@ -1,0 +1,132 @@
+"""Seeded parity fuzz under -m gpu (review of round 4, item 3): random configurations of every policy, HIP path vs the CPU oracle.
+
+Exact stages (a failure is a bug): indices == canonical top-k of the kernel's own scores, K/V == the exact gather, Ada-SnapKV
+budgets == the oracle's arithmetic on the kernel's scores, LOOK-M merge == the oracle on the selected indices.
+Floating-point stage: tests/score_bar.py - every score within 1 ulp of the oracle or reproduced by the oracle with one
+product q.k of that position rounded to its neighbour; no tolerance is loosened for these seeds.
+A fixed number of cases per seed (not a time budget): the set of cases does not depend on the speed of the box."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from inputs import make_qkv
+from oracle import pkv_oracle as O
+from score_bar import check_h2o_scores, check_window_scores
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CASES_PER_SEED = 70
+SMAX = 3000
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyramidkv_amd
+    return pyramidkv_amd
+
+
+@pytest.mark.parametrize("seed", [424242, 20260925, 777])
+def test_parity_fuzz_seed(P, seed):
+    from pyramidkv_amd import config as cfg
+    rng = np.random.RandomState(seed)
+    n = 0
+    kinds = {}
+    fp = dict(score_checks=0, checks_with_an_element_beyond_1ulp=0, elements_beyond_1ulp=0, reproduced_exactly=0,
+              reproduced_within_1ulp=0, max_ulp=0, max_mismatch_frac=0.0)
+
+    def note(rep):
+        fp["score_checks"] += 1
+        fp["checks_with_an_element_beyond_1ulp"] += rep["beyond_1ulp"] > 0
+        fp["elements_beyond_1ulp"] += rep["beyond_1ulp"]
+        fp["reproduced_exactly"] += rep["reproduced_exactly"]
+        fp["reproduced_within_1ulp"] += rep["reproduced_within_1ulp"]
+        fp["max_ulp"] = max(fp["max_ulp"], rep["max_ulp"])
+        fp["max_mismatch_frac"] = max(fp["max_mismatch_frac"], rep["mismatch_frac"])
+
+    old_short = cfg.ada_short_lists
+    try:
+        while n < CASES_PER_SEED:
+            pol = str(rng.choice(["window", "window", "h2o", "adakv", "merge", "pyramid"]))
+            S = int(rng.randint(40, SMAX)) if pol != "h2o" else int(rng.randint(40, 1500))
+            w = int(rng.choice([1, 4, 8, 8, 16, 32, 64]))
+            if S <= w + 8:
+                continue
+            G = int(rng.choice([1, 2, 4]))
+            H = G * int(rng.randint(1, 5))
+            B = 1 if pol == "adakv" else int(rng.randint(1, 3))
+            dt = ("bf16", "fp16")[int(rng.randint(0, 2))]
+            kind = ("gauss", "lattice", "planted")[int(rng.randint(0, 3))]
+            pool, ks = [("maxpool", 7), ("avgpool", 5), ("maxpool", 17), ("avgpool", 13), (None, 1), ("maxpool", 3)][int(rng.randint(0, 6))]
+            L = S - w
+            kk = int(rng.randint(1, L + 1)) if rng.rand() < 0.7 else int(rng.choice([1, L, min(L, 512), min(L, 513), min(L, 2040)]))
+            q, k, v = make_qkv(B, H, S, 128, dt, kind, int(rng.randint(0, 1 << 30)))
+            ku, vu = k[:, ::G].contiguous(), v[:, ::G].contiguous()
+            ke, ve = ku.repeat_interleave(G, dim=1), vu.repeat_interleave(G, dim=1)
+            qd, kd, vd = q.to(DEV), ku.to(DEV), vu.to(DEV)
+            tag = dict(seed=seed, case=n, pol=pol, B=B, H=H, G=G, S=S, w=w, dt=dt, kind=kind, pool=pool, ks=ks, k=kk)
+            if pol in ("window", "pyramid", "merge"):
+                got = P.ops.score_window(qd, kd, w, pool, ks, kv_group=G).cpu()
+                note(check_window_scores(q, ke, w, pool, ks, "sum", got, lambda: P.ops.score_window(qd, kd, w, None, 1, kv_group=G).cpu(),
+                                         frac_bar=2e-2, what=tag))
+                kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk, pool, ks, kv_group=G, return_indices=True)
+                idx = idx.cpu().long()
+                assert torch.equal(idx, O.topk_canonical(got, kk)), ("indices", tag)
+                kr, vr = O.gather_compact(ke, ve, idx, w)
+                assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), ("gather", tag)
+                if pol == "pyramid" and pool is not None:
+                    layer = int(rng.randint(0, 32))
+                    cap = w + kk
+                    cl = P.PyramidKVCluster(num_hidden_layers=32, layer_idx=layer, window_size=w, max_capacity_prompt=cap, kernel_size=ks, pooling=pool)
+                    kc, vc = cl.update_kv(kd, qd, vd, None, G)
+                    kr, vr = O.pyramidkv_update_kv(ke, q, ve, w, cap, ks, pool, 32, layer)
+                    assert kc.shape == kr.shape, ("pyramid shape", tag)
+                    kc2, vc2 = cl.update_kv(kd, qd, vd, None, G)                        # the prepared call of the same cluster
+                    assert torch.equal(kc2, kc) and torch.equal(vc2, vc), ("prepared call", tag)
+                if pol == "merge" and pool is not None and kk + w <= 4000:
+                    km, vm = P.ops.merge_compact(kd, vd, P.ops.select(qd, kd, w, kk, pool, ks, kv_group=G), w, kv_group=G)
+                    kmr, vmr = O.merge_kv(ke, ve, idx, w, "pivot")
+                    assert torch.equal(km.cpu(), kmr) and torch.equal(vm.cpu(), vmr), ("merge", tag)
+            elif pol == "h2o":
+                got = P.ops.score_h2o(qd, kd, w, kv_group=G).cpu()
+                want = O.h2o_scores(q, ke, w)
+                tiny = want.float().abs() < 1e-35                   # flushed by the hardware exp2 / the MFMA operands
+                got_c = torch.where(tiny, want, got)
+                note(check_h2o_scores(q, ke, w, got_c, frac_bar=2e-2, what=tag))
+                kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk, None, 1, kv_group=G, h2o=True, return_indices=True)
+                assert torch.equal(idx.cpu().long(), O.topk_canonical(got, kk)), ("h2o indices", tag)
+                kr, vr = O.gather_compact(ke, ve, idx.cpu().long(), w)
+                assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr), ("h2o gather", tag)
+            else:   # adakv
+                if pool is None:
+                    pool, ks = "maxpool", 7
+                floor = float(rng.choice([0.0, 0.2, 0.5, 1.0]))
+                norm = bool(rng.randint(0, 2))
+                cap = w + max(1, min(kk, L // 2))
+                cfg.ada_short_lists = int(rng.choice([0, 1, 2, 4]))
+                tag.update(floor=floor, norm=norm, cap=cap, short=cfg.ada_short_lists)
+                cl = P.AdaKVCluster(window_size=w, kernel_size=ks, pooling=pool, max_capacity_prompt=cap, floor=floor, normalize=norm)
+                kf, vf = cl.update_kv(kd, qd, vd)
+                kf2, vf2 = cl.update_kv(kd, qd, vd)                                     # second call: the prepared path
+                assert torch.equal(kf2, kf) and torch.equal(vf2, vf), ("ada prepared call", tag)
+                cfg.ada_short_lists = old_short
+                sg = P.ops.score_window(qd, kd, w, pool, ks, "mean", kv_group=G).cpu()[0]
+                sidx, caps = O.adakv_head_capacity(sg[None], cap - w, floor, norm)
+                caps = caps[0].tolist()
+                assert cl.head_lens.cpu().tolist() == [c + w for c in caps], ("ada budgets", tag)
+                rows_k, rows_v = [], []
+                for h in range(H):
+                    ix = sidx[0, h, :caps[h]].long()
+                    rows_k += [ke[0, h, ix], ke[0, h, L:]]
+                    rows_v += [ve[0, h, ix], ve[0, h, L:]]
+                assert torch.equal(kf.cpu(), torch.cat(rows_k)) and torch.equal(vf.cpu(), torch.cat(rows_v)), ("ada flat gather", tag)
+            n += 1
+            kinds[pol] = kinds.get(pol, 0) + 1
+    finally:
+        cfg.ada_short_lists = old_short
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_fuzz_seed%d.json" % seed), "w") as f:
+        json.dump(dict(seed=seed, cases=n, by_policy=kinds, floating_point=fp), f, indent=1)
