@@ -143,7 +143,7 @@ size_t topk_tmp_bytes(int rows, int L, int k);
 
 struct WsLayout {
   int Sp, nT, Lp;
-  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_tk, tk_bytes, off_ada, off_ada_list, off_rowstat, off_knorm, total;
+  size_t off_logits, off_partial, off_scores, off_idx, off_cmax, off_tk, tk_bytes, off_ada, off_ada_list, off_rowstat, total;
 };
 
 WsLayout ws_layout(const pkv_desc* d) {
@@ -165,7 +165,6 @@ WsLayout ws_layout(const pkv_desc* d) {
   w.off_ada = o;     o = align_up(o + 1024 + (size_t)2 * d->H * 256 * 4, 256);                 // Ada-SnapKV budget scratch (pkv_ada_select)
   w.off_ada_list = o; o = align_up(o + (size_t)d->H * align_up((size_t)(d->topk > 0 ? d->topk : 1), 8) * 2, 256);   // looked-up top-M lists
   w.off_rowstat = o; o = align_up(o + (size_t)d->B * d->H * d->S * sizeof(float2), 256);   // H2O only: c_row of every query row (fp32 tensors: (max, 1/sum) pairs)
-  w.off_knorm = o;   o = align_up(o + (size_t)d->B * d->H * 64 * sizeof(float), 256);       // H2O only: partial key-norm maxima
   w.total = o;
   return w;
 }
@@ -271,7 +270,6 @@ int do_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores, 
   H2OParams hp;
   hp.q = q; hp.k = k;
   hp.rowstat = reinterpret_cast<float*>(ws + L.off_rowstat);
-  hp.knorm = reinterpret_cast<float*>(ws + L.off_knorm);
   hp.scores = scores; hp.scores_stride = stride;
   hp.B = d->B; hp.H = d->H; hp.S = d->S; hp.w = d->window; hp.G = d->kv_group; hp.D = d->D;
   hp.qs_b = d->q_stride[0]; hp.qs_h = d->q_stride[1]; hp.qs_s = d->q_stride[2];
@@ -285,14 +283,12 @@ int do_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores, 
     return e == hipSuccess ? PKV_OK : hip_fail(e);
   }
   {
-    ProfScope ps(PKV_K_H2O_STATS, st);                                       // key-norm scan + statistics pass
-    hipError_t e = launch_h2o_knorm(d->dtype, hp, st);
-    if (e != hipSuccess) return hip_fail(e);
-    e = launch_h2o_stats(d->dtype, hp, st);
+    ProfScope ps(PKV_K_H2O_STATS, st, true);                                 // statistics pass
+    hipError_t e = launch_h2o_stats(d->dtype, hp, st);
     if (e != hipSuccess) return hip_fail(e);
   }
   {
-    ProfScope ps(PKV_K_H2O_COLSUM, st);
+    ProfScope ps(PKV_K_H2O_COLSUM, st, true);
     hipError_t e = launch_h2o_colsum(d->dtype, hp, st);
     if (e != hipSuccess) return hip_fail(e);
   }

@@ -6,7 +6,6 @@
 //     score[j] = sum_i P[i][j] for j < S-w (fp32 accumulate, one rounding).
 //
 // S x S is never materialised (68.7 GB bf16 at S=32k).  Two MFMA passes over the S x S tile space:
-//   h2o_knorm_kernel   per KV head: the largest squared key norm (64 partial maxima; a 45 us scan of K)
 //   h2o_stats_kernel   per query row: c_row = -log2 sum_j exp(x_ij)  (softmax denominator, log domain)
 //   h2o_colsum_kernel  per key column: sum over all query rows of round(exp2(x*log2e + c_row))
 // Both big passes recompute the logits with mfma_f32_16x16x32 and apply the reference's three roundings.
@@ -25,14 +24,14 @@
 // h2o_wide_pipeline.hip: 14.5 % fewer cycles in pass 1, 7 % faster on zero-filled operands, but clocked 8 % lower on N(0,1)
 // data and 3 % SLOWER there than the kernels below; its accumulators move twice the register bytes per flop).
 // The levers that are in:
-//   * no running maximum in pass 1 (round 4).  softmax needs SOME reference point M_i with exp(x - M_i) in fp32 range, not
-//     the maximum: M_i = |q_i| * max_j|k_j| / sqrt(D) * 1.02 - 64 is an upper bound of every logit of the row (Cauchy-
-//     Schwarz on the rounded operands, 2 % for the two roundings) shifted so that a row maximum anywhere in
-//     [bound - 105, bound] keeps Z_i = sum exp(x - M_i) inside [2^-60, 2^112]: 6 vector instructions per element (round,
-//     scale, round, fma, exp2, add) instead of 6.75 + a wave-uniform branch per 4 elements.  A workgroup whose rows leave
-//     that window (Z < 2^-60, inf or NaN: key norms far above what the row actually attends to) repeats its rows with
-//     the exact online maximum - same kernel, second instance of the loop.  c_row = mL - log2 Z does not depend on the
-//     reference point, so pass 2 does not care;
+//   * no running maximum in pass 1 (round 4; reference point changed in round 5).  softmax needs SOME reference point M_i
+//     with exp(x - M_i) in fp32 range, not the maximum: M_i = the lane's maximum over the FIRST 64-key tile (tracked there,
+//     then frozen; a real prompt's attention sinks sit in that tile).  Z_i >= 1 and everything up to +88 above the sampled
+//     maximum still sums in range: 6 vector instructions per element (round, scale, round, fma, exp2, add) instead of
+//     6.75 + a wave-uniform branch per 4 elements.  A workgroup with a row whose Z overflowed repeats its rows with the
+//     exact online maximum - same kernel, second instance of the loop.  c_row = -(m log2e + log2 Z) does not depend on
+//     the reference point, so pass 2 does not care.  (Round 4's point was a norm bound |q_i| max_j|k_j| / sqrt(D) - 64 from
+//     a key-norm scan: one large-norm key that no row attends to put every row outside its window - the advisor's finding;)
 //   * bf16 rounding as v_cvt_pk_bf16_f32 v, 0, x: the rounded value lands in the HIGH half over a zero low half, which
 //     IS its fp32 representation - 1 instruction per rounding instead of pack + shift/mask (1.5);
 //   * no packed-fp32 arithmetic (v_pk_mul/fma_f32 cost several issue slots beside MFMAs): compiled with -fno-slp-vectorize;
@@ -172,74 +171,29 @@ __device__ __forceinline__ void load_frags(u32x4 (&f)[KS], const uint16_t* base,
 }
 // the 16 MFMAs of one 16-row sub-tile (fragments f, the A operand) against the wave's 64 resident rows (B): four
 // independent accumulators back to back, no dependent-MFMA stall.  D[streamed row][resident row].
+// H2O_SETPRIO (A/B knob, tools/build_h2o_variants.sh; default off): wave priority around the MFMA group.  1 = the wave that is
+// issuing MFMAs outranks the waves in their vector epilogues; 2 = the opposite (the epilogue waves win the issue slots an
+// MFMA leaves free).  Measured in round 5: see profiles/r05/h2o_setprio_ab.txt.
+#ifndef H2O_SETPRIO
+#define H2O_SETPRIO 0
+#endif
 template <typename T, int KS>
 __device__ __forceinline__ void mm16(f32x4 (&acc)[4], const u32x4 (&f)[KS], const u32x4 (&res)[4][KS]) {
 #pragma unroll
   for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (H2O_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
+  if (H2O_SETPRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = Mfma2<T>::run(f[kk], res[n][kk], acc[n]);
-}
-
-constexpr int NCH = 64;                // partial key-norm maxima per KV head
-template <typename T> __device__ __forceinline__ float sumsq8(u32x4 v);
-template <> __device__ __forceinline__ float sumsq8<BF16>(u32x4 v) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float lo = __uint_as_float(v[i] << 16), hi = __uint_as_float(v[i] & 0xffff0000u);
-    s = __builtin_fmaf(lo, lo, s); s = __builtin_fmaf(hi, hi, s);
-  }
-  return s;
-}
-template <> __device__ __forceinline__ float sumsq8<F16>(u32x4 v) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float lo = Elem<F16>::to_f32((uint16_t)(v[i] & 0xffffu)), hi = Elem<F16>::to_f32((uint16_t)(v[i] >> 16));
-    s = __builtin_fmaf(lo, lo, s); s = __builtin_fmaf(hi, hi, s);
-  }
-  return s;
-}
-
-// Largest squared key norm of every KV head, as NCH partial maxima (pass 1 reduces them in its prologue).
-template <typename T, int KS>
-__global__ __launch_bounds__(256) void h2o_knorm_kernel(H2OParams p) {
-  constexpr int CPR = 4 * KS, RPP = 256 / CPR;
-  __shared__ float wmax[4];
-  const int tid = threadIdx.x;
-  const int Hkv = p.H / p.G;
-  const int bhk = blockIdx.y, b = bhk / Hkv, hk = bhk - b * Hkv;
-  const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
-  const int rpc = (p.S + NCH - 1) / NCH;
-  const int r0 = blockIdx.x * rpc, r1 = min(p.S, r0 + rpc);
-  const int c = tid % CPR;
-  float mx = 0.f;
-  for (int r = r0 + tid / CPR; r < r1; r += 4 * RPP) {
-    float s[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                                          // four row loads in flight
-      const int rr = r + i * RPP;
-      const u32x4 v = rr < r1 ? *reinterpret_cast<const u32x4*>(kb + (int64_t)rr * p.ks_s + c * 8) : u32x4{0, 0, 0, 0};
-      s[i] = sumsq8<T>(v);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int o = 1; o < CPR; o <<= 1) s[i] += __shfl_xor(s[i], o, 64);   // the CPR lanes of a row are neighbours
-      mx = fmaxf(mx, s[i] == s[i] ? s[i] : INFINITY);                      // NaN keys: no finite bound, the exact loop runs
-    }
-  }
-  mx = wave_max(mx);
-  if ((tid & 63) == 0) wmax[tid >> 6] = mx;
-  __syncthreads();
-  if (tid == 0) p.knorm[(int64_t)bhk * NCH + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  if (H2O_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
+  if (H2O_SETPRIO == 2) __builtin_amdgcn_s_setprio(1);
 }
 
 // Pass 1: per query row, c_row = -log2 sum_j exp(x_ij).  Resident = 256 query rows, streamed = K.
-// Per-lane statistics (lane's column = one query, 4 keys per 16-key subtile).  Bound path: exponentials relative to the row's
-// norm bound, no maximum; exact path (rows outside the window): the running maximum is only rescaled when some lane of the
+// Per-lane statistics (lane's column = one query, 4 keys per 16-key subtile).  Frozen path: exponentials relative to the lane's
+// maximum over the first tile; exact path (a row overflowed): the running maximum is only rescaled when some lane of the
 // wave actually found a larger logit (wave-uniform branch).
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
@@ -262,22 +216,6 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
   }
   const float L2E = 1.44269504088896340736f;
   float m[4], mL[4], Z[4];          // running max, -max*log2e, running sum of exp
-  // reference point of the bound path: upper bound of every logit of the row, shifted down by 64
-  const float kmax2 = wave_max(p.knorm[((int64_t)b * (p.H / p.G) + hk) * NCH + lane]);
-  float mL0[4];
-  bool wild = false;
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    float s = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) s += sumsq8<T>(qf[n][kk]);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    const float ub = __builtin_sqrtf(s * kmax2) * 1.02f;
-    wild |= !(ub < INFINITY);
-    mL0[n] = (64.0f - ub * p.rcp_sqrt_d) * L2E;
-  }
-
   const TileStream ks = make_stream<KS>(kb, p.ks_s, S, tid);
   Stager<KS> stg;
   stage_load<KS>(stg, ks, 0);
@@ -332,51 +270,55 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
   };
   const int t_plain = (L < S ? L : S) / HT;                                   // tiles [0, t_plain) end at or before L
   float* rs = p.rowstat + (int64_t)bh * S;
-  if (!__syncthreads_or(wild)) {
+  // Reference point of the exponentials (round 5): the lane's maximum over the FIRST tile of keys, then frozen.  softmax needs
+  // some M_i with exp(x - M_i) inside the fp32 range, not the row maximum; tile 0 holds what a row of a real prompt attends to
+  // first (the attention sinks) and is a sample of 64 keys otherwise, so the row maximum lies within a few units of it - and
+  // anything up to +88 above it still sums without overflow.  Z >= 1 by construction (the sampled maximum itself contributes
+  // 1), so only Z = inf / NaN sends a workgroup through the exact online-maximum loop again.  Round 4 took the point from a
+  // norm bound |q_i| max_j |k_j| / sqrt(D) - 64 instead (a key-norm scan + 20 instructions per row): right for N(0,1) data,
+  // but a single massive-activation key nobody attends to pushed every row out of its window and doubled the pass
+  // (the advisor's finding); the sample costs the tracking body for one tile in 512 and no extra kernel.
 #pragma unroll
-    for (int n = 0; n < 4; ++n) { m[n] = 0.f; mL[n] = mL0[n]; Z[n] = 0.f; }
-    for (int t = 0; t < t_plain; ++t) tile_body(t, std::false_type{}, std::false_type{});
-    for (int t = t_plain; t < ntiles; ++t) tile_body(t, std::true_type{}, std::false_type{});
+  for (int n = 0; n < 4; ++n) { m[n] = -INFINITY; mL[n] = 0.f; Z[n] = 0.f; }
+  auto finish = [&](bool check) -> bool {        // merge the four key groups of every query row; -> true when some row overflowed
+    float cr[4];
     bool bad = false;
-    float zt[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      zt[n] = Z[n] + __shfl_xor(Z[n], 16, 64);
-      zt[n] += __shfl_xor(zt[n], 32, 64);
-      bad |= !(zt[n] >= 0x1p-60f && zt[n] <= 0x1p120f);
-    }
-    if (!__syncthreads_or(bad)) {
+      float mm = m[n], zz = Z[n];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int e = __builtin_amdgcn_frexp_expf(zt[n]);
-        const float f = __builtin_amdgcn_frexp_mantf(zt[n]);
-        if (lg == 0 && qi[n] < S) rs[qi[n]] = (mL[n] - (float)e) - __builtin_amdgcn_logf(f);
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float mo = __shfl_xor(mm, o, 64), zo = __shfl_xor(zz, o, 64);
+        const float mn = fmaxf(mm, mo);
+        const float za = (mm == -INFINITY) ? 0.f : zz * __builtin_amdgcn_exp2f((mm - mn) * L2E);
+        const float zb = (mo == -INFINITY) ? 0.f : zo * __builtin_amdgcn_exp2f((mo - mn) * L2E);
+        mm = mn; zz = za + zb;
       }
-      return;
+      bad |= !(zz <= 0x1p120f);                                              // inf or NaN (a row that sees no key at all does not exist)
+      // c_row = -(m*log2e + log2 Z): pass 2 evaluates exp(x - m) / Z as exp2(x*log2e + c_row); independent of the reference point
+      cr[n] = -(mm * L2E + __builtin_amdgcn_logf(zz));
     }
+    if (check && __syncthreads_or(bad)) return true;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      if (lg == 0 && qi[n] < S) rs[qi[n]] = cr[n];
+    return false;
+  };
+  {
+    if (t_plain > 0) tile_body(0, std::false_type{}, std::true_type{}); else tile_body(0, std::true_type{}, std::true_type{});
+    for (int t = 1; t < t_plain; ++t) tile_body(t, std::false_type{}, std::false_type{});
+    for (int t = t_plain > 1 ? t_plain : 1; t < ntiles; ++t) tile_body(t, std::true_type{}, std::false_type{});
+    if (!finish(true)) return;
     // repeat with the exact online maximum: restage tile 0
     stage_load<KS>(stg, ks, 0);
     stage_store<KS>(stg, tiles[0], tid);
     __syncthreads();
-  }
 #pragma unroll
-  for (int n = 0; n < 4; ++n) { m[n] = -INFINITY; mL[n] = 0.f; Z[n] = 0.f; }
+    for (int n = 0; n < 4; ++n) { m[n] = -INFINITY; mL[n] = 0.f; Z[n] = 0.f; }
+  }
   for (int t = 0; t < t_plain; ++t) tile_body(t, std::false_type{}, std::true_type{});
   for (int t = t_plain; t < ntiles; ++t) tile_body(t, std::true_type{}, std::true_type{});
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    float mm = m[n], zz = Z[n];
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-      const float mo = __shfl_xor(mm, o, 64), zo = __shfl_xor(zz, o, 64);
-      const float mn = fmaxf(mm, mo);
-      const float za = (mm == -INFINITY) ? 0.f : zz * __builtin_amdgcn_exp2f((mm - mn) * L2E);
-      const float zb = (mo == -INFINITY) ? 0.f : zo * __builtin_amdgcn_exp2f((mo - mn) * L2E);
-      mm = mn; zz = za + zb;
-    }
-    // c_row = -(m*log2e + log2 Z): pass 2 evaluates exp(x - m) / Z as exp2(x*log2e + c_row)
-    if (lg == 0 && qi[n] < S) rs[qi[n]] = -(mm * L2E + __builtin_amdgcn_logf(zz));
-  }
+  finish(false);
 }
 
 // Pass 2: per key column, sum over all query rows of round(exp(x - m) / Z).  Resident = 256 key columns,
@@ -466,16 +408,6 @@ static bool strides_ok(const H2OParams& p) {
   return p.qs_s > 0 && p.ks_s > 0 && p.qs_s * 2 * 64 < (int64_t)0xffffffffll && p.ks_s * 2 * 64 < (int64_t)0xffffffffll;
 }
 
-hipError_t launch_h2o_knorm(int dtype, const H2OParams& p, hipStream_t st) {
-  if (!strides_ok(p)) return hipErrorInvalidValue;
-  dim3 grid(NCH, p.B * (p.H / p.G));
-#define PKV_H2O_N(TT, KS) hipLaunchKernelGGL((h2o_knorm_kernel<TT, KS>), grid, dim3(256), 0, st, p)
-  if (dtype == 0) { if (p.D == 64) PKV_H2O_N(BF16, 2); else if (p.D == 256) PKV_H2O_N(BF16, 8); else PKV_H2O_N(BF16, 4); }
-  else { if (p.D == 64) PKV_H2O_N(F16, 2); else if (p.D == 256) PKV_H2O_N(F16, 8); else PKV_H2O_N(F16, 4); }
-#undef PKV_H2O_N
-  return hipGetLastError();
-}
-
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
   if (!strides_ok(p)) return hipErrorInvalidValue;
   dim3 grid((p.S + HWG - 1) / HWG, p.B * p.H);
@@ -486,7 +418,7 @@ hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st) {
       hipError_t e_ = dyn_lds(reinterpret_cast<const void*>(h2o_stats_kernel<TT, KS>), lds_);                    \
       if (e_ != hipSuccess) return e_;                                                                                \
     }                                                                                                                 \
-    hipLaunchKernelGGL((h2o_stats_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                     \
+    PKV_KLAUNCH((h2o_stats_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                            \
   } while (0)
   if (dtype == 0) { if (p.D == 64) PKV_H2O_S(BF16, 2); else if (p.D == 256) PKV_H2O_S(BF16, 8); else PKV_H2O_S(BF16, 4); }
   else { if (p.D == 64) PKV_H2O_S(F16, 2); else if (p.D == 256) PKV_H2O_S(F16, 8); else PKV_H2O_S(F16, 4); }
@@ -505,7 +437,7 @@ hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st) {
       hipError_t e_ = dyn_lds(reinterpret_cast<const void*>(h2o_colsum_kernel<TT, KS>), lds_);                    \
       if (e_ != hipSuccess) return e_;                                                                                \
     }                                                                                                                 \
-    hipLaunchKernelGGL((h2o_colsum_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                    \
+    PKV_KLAUNCH((h2o_colsum_kernel<TT, KS>), grid, dim3(256), lds_, st, p);                                           \
   } while (0)
   if (dtype == 0) { if (p.D == 64) PKV_H2O_C(BF16, 2); else if (p.D == 256) PKV_H2O_C(BF16, 8); else PKV_H2O_C(BF16, 4); }
   else { if (p.D == 64) PKV_H2O_C(F16, 2); else if (p.D == 256) PKV_H2O_C(F16, 8); else PKV_H2O_C(F16, 4); }

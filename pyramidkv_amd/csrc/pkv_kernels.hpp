@@ -205,7 +205,6 @@ struct H2OParams {
   const void* q;
   const void* k;
   float* rowstat;     // [B*H][S] c_row = -log2 sum_j exp(x_ij) of every query row
-  float* knorm;       // [B*(H/G)][64] partial maxima of the squared key norms (h2o_knorm_kernel)
   void* scores;
   int64_t scores_stride;
   int B, H, S, w, G;
@@ -252,7 +251,6 @@ hipError_t launch_finalize_f32(const FinalizeParams& p, hipStream_t st);
 hipError_t launch_topk_f32(int rows, const TopkParams& p, hipStream_t st);
 int topk_f32_max_k();
 hipError_t launch_h2o_f32(const H2OParams& p, hipStream_t st);            // fp32 tensors (pkv_f32.hip): rowstat = float2 (max, 1/sum) per row
-hipError_t launch_h2o_knorm(int dtype, const H2OParams& p, hipStream_t st);
 hipError_t launch_h2o_stats(int dtype, const H2OParams& p, hipStream_t st);
 hipError_t launch_h2o_colsum(int dtype, const H2OParams& p, hipStream_t st);
 

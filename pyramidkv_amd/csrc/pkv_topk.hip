@@ -203,9 +203,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
   __syncthreads();
   if (PKV_TRACE(p) && tid == 0 && row == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PKV_TRACE(p)[7] = (unsigned long long)clock64(); }
-  if (ADA) {
-    // sum over all scores of the row (:710 `attn_score.sum(dim=-1)`), fp64 like ada_stats_kernel: this wave's share goes out
-    // as one partial, the 16 partials are added in wave order by the budget kernel (a fixed order: run-to-run identical)
+  // ADA: sum over all scores of the row (:710 `attn_score.sum(dim=-1)`), fp64 like ada_stats_kernel: this wave's share goes
+  // out as one partial, the 16 partials are added in wave order by the budget kernel (a fixed order: run-to-run identical).
+  // It needs the WHOLE row in registers, so it runs where the row has arrived anyway: in the small-k path after the threshold
+  // search on the chunk maxima (which arrive first and hide the row's cold round trip), not right behind the loads.
+  auto row_sum = [&]() {
     double sa = 0.0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64);
     if (lane == 0) p.rowsum_out[(int64_t)vrow * TK_WAVES + wave] = sa;
-  }
+  };
   U4 kreg[8];     // this lane's ordered keys (niter chunks of 8), kept in registers for every later pass
   auto transform_all = [&]() {
 #pragma unroll
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     }
   };
   const bool fast2 = fast_ok && dual && vec_ok && p.algo == 1;      // one-level fast path, see below
+  if (ADA && !(fast2 && use_cmax)) row_sum();
   if (!use_cmax && !fast2) transform_all();
 
   // ---- one-level fast path (algo 1, small k).  Cost model: 1024 threads on one CU = every wave-instruction costs
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       xstar = (cb * 32 + (uint32_t)src2) << 3;
     }
     PKV_STAMP(1);
+    if (ADA && use_cmax) row_sum();
     // stage the passing chunks: one LDS atomic per wave reserves the slots of all its passing chunks
     {
       // (the pass masks are recomputed in the second loop instead of being kept: 8 live 64-bit masks push this kernel over

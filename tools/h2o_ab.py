@@ -9,7 +9,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     from pyramidkv_amd import _native as N
     S = int(sys.argv[2])
     g = torch.Generator(device="cuda").manual_seed(5)
-    q, k = (torch.randn(1, 32, S, 128, device="cuda", generator=g).to(torch.bfloat16) for _ in range(2))
+    q, k = (torch.randn(1, 32, S, 128, device="cuda", generator=g) for _ in range(2))
+    sc_ = float(os.environ.get("H2O_SCALE", "1"))          # q, k x scale: logits x scale^2 (large-norm models)
+    q, k = q * sc_, k * sc_
+    if os.environ.get("H2O_OUTLIER"):                      # one massive-activation key per head that no query attends to
+        k[:, :, 7] = -q[:, :, -64:].mean(2) * float(os.environ["H2O_OUTLIER"])
+    q, k = q.to(torch.bfloat16), k.to(torch.bfloat16)
     for _ in range(2):
         sc = P.ops.score_h2o(q, k, 8)
     torch.cuda.synchronize()
