@@ -48,7 +48,7 @@ enum pkv_status {
 
 /* PKV_F32: pkv_score_window, pkv_score_h2o, pkv_topk(_ws), pkv_gather_compact, pkv_gather_streaming, pkv_gather_flat,
  * pkv_compress, pkv_compress_h2o, pkv_select, pkv_merge_compact, pkv_ada_budget_rows, pkv_ada_metadata and
- * pkv_update_flatten_view, D in {64,128}, topk <= 4096; every other entry point (pkv_sort_rows, pkv_ada_budget,
+ * pkv_update_flatten_view, D in {64,128,256} (256 since 0.2.0), topk <= 4096; every other entry point (pkv_sort_rows, pkv_ada_budget,
  * pkv_ada_budget_topm, pkv_ada_adaptive_lists, pkv_ada_select) answers PKV_ERR_DTYPE / PKV_ERR_UNSUPPORTED. */
 enum pkv_dtype { PKV_BF16 = 0, PKV_F16 = 1, PKV_F32 = 2 };
 enum pkv_pool { PKV_POOL_NONE = 0, PKV_POOL_AVG = 1, PKV_POOL_MAX = 2 };
@@ -158,7 +158,7 @@ PKV_API int pkv_select(const pkv_desc* d, const void* q, const void* k, int32_t 
  * [window, selected] (:146) and v_out [selected, window] (:148), and the value merge uses the key order's pivot numbers.
  * idx: int32 [B*H][idx_stride] (d->topk = k entries per row, from pkv_select / pkv_topk).  Outputs [B,H,k+w,D] contiguous.
  * ws: pkv_merge_workspace_bytes(d), 16-B aligned.  Rounding points: oracle/pkv_oracle.py merge_kv_explicit.
- * bf16 / fp16 at D = 64 / 128 / 256, fp32 (since 0.1.2) at D = 64 / 128 and topk <= 4096; S <= 393 216 and
+ * bf16 / fp16 / fp32 (since 0.1.2; D = 256 since 0.2.0) at D = 64 / 128 / 256, fp32 with topk <= 4096; S <= 393 216 and
  * k + window <= 65 535 (PKV_ERR_UNSUPPORTED beyond). */
 PKV_API size_t pkv_merge_workspace_bytes(const pkv_desc* d);
 PKV_API int pkv_merge_compact(const pkv_desc* d, const void* k, const void* v, const int32_t* idx, int64_t idx_stride,

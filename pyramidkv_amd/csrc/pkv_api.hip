@@ -119,7 +119,7 @@ int check_desc(const pkv_desc* d, bool need_topk, bool scoring = true, bool f32_
   if (!d) return PKV_ERR_NULL;
   if (d->dtype != PKV_BF16 && d->dtype != PKV_F16 && d->dtype != PKV_F32) return PKV_ERR_DTYPE;
   if (d->D != 64 && d->D != 128 && d->D != 256) return PKV_ERR_SHAPE;
-  if (d->dtype == PKV_F32 && (!f32_ok || d->D == 256)) return PKV_ERR_UNSUPPORTED;
+  if (d->dtype == PKV_F32 && !f32_ok) return PKV_ERR_UNSUPPORTED;
   if (d->B < 1 || d->H < 1 || d->S < 2) return PKV_ERR_SHAPE;
   if (d->kv_group < 1 || d->H % d->kv_group) return PKV_ERR_SHAPE;
   if (d->window < 1 || d->window >= d->S) return PKV_ERR_SHAPE;

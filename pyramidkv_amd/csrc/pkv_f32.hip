@@ -503,6 +503,7 @@ hipError_t launch_budget_f32(const BudgetParams& p, hipStream_t st) {
 hipError_t launch_logits_f32(const LogitsParams& p, hipStream_t st) {
   dim3 grid(p.nT, p.B * (p.H / p.G));
   if (p.D == 64) PKV_KLAUNCH(logits_f32_kernel<4>, grid, dim3(256), 0, st, p);
+  else if (p.D == 256) PKV_KLAUNCH(logits_f32_kernel<16>, grid, dim3(256), 0, st, p);     // round 5: the reference takes any head size in fp32 too
   else PKV_KLAUNCH(logits_f32_kernel<8>, grid, dim3(256), 0, st, p);
   return hipGetLastError();
 }
@@ -627,6 +628,9 @@ hipError_t launch_h2o_f32(const H2OParams& p, hipStream_t st) {
   if (p.D == 64) {
     hipLaunchKernelGGL(h2o_stats_f32_kernel<4>, g1, dim3(256), 0, st, p);
     hipLaunchKernelGGL(h2o_colsum_f32_kernel<4>, g2, dim3(256), 0, st, p);
+  } else if (p.D == 256) {
+    hipLaunchKernelGGL(h2o_stats_f32_kernel<16>, g1, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(h2o_colsum_f32_kernel<16>, g2, dim3(256), 0, st, p);
   } else {
     hipLaunchKernelGGL(h2o_stats_f32_kernel<8>, g1, dim3(256), 0, st, p);
     hipLaunchKernelGGL(h2o_colsum_f32_kernel<8>, g2, dim3(256), 0, st, p);

@@ -19,7 +19,7 @@ namespace pkv {
 // for speed only): the indices of head bh were written by top-k workgroup bh, i.e. on XCD bh % 8, and the gather
 // blocks of that head are placed on the same XCD, where the index lines are still in the L2 - the one dependent
 // round trip before any row can move is then an L2 hit instead of a trip to the fabric.
-// CH = 16-B chunks per row = head_dim / 8 (8, 16, 32 for head sizes 64, 128, 256): 256 / CH row slots per pass.
+// CH = 16-B chunks per row = head_dim / 8 (8, 16, 32 for head sizes 64, 128, 256; 64 = fp32 rows of head size 256): 256 / CH row slots per pass.
 template <int RPT, int CH>
 __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
   constexpr int SLOTS = 256 / CH;
@@ -119,6 +119,8 @@ hipError_t launch_gather(const GatherParams& p0, int max_rows, hipStream_t st) {
     if (rpt == 2) PKV_G(2, 16); else if (rpt == 16) PKV_G(16, 16); else if (rpt == 8) PKV_G(8, 16); else PKV_G(4, 16);
   } else if (ch == 8) {
     if (rpt == 2) PKV_G(2, 8); else if (rpt == 8) PKV_G(8, 8); else PKV_G(4, 8);
+  } else if (ch == 64) {                                    // 1024-byte rows: fp32 tensors at head size 256
+    if (rpt == 2) PKV_G(2, 64); else if (rpt == 8) PKV_G(8, 64); else PKV_G(4, 64);
   } else {
     if (rpt == 2) PKV_G(2, 32); else if (rpt == 8) PKV_G(8, 32); else PKV_G(4, 32);
   }

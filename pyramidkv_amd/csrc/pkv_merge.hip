@@ -646,7 +646,7 @@ hipError_t launch_merge(int dtype, const MergeParams& p, hipStream_t st) {
   const int mb = (int)std::min<int64_t>((total + 255) / 256, 1024);
   hipLaunchKernelGGL(merge_mark_kernel, dim3(mb), dim3(256), 0, st, p);
   hipLaunchKernelGGL(merge_droplist_kernel, dim3(1), dim3(1024), 0, st, p);
-  if (dtype == 2) return p.D == 64 ? launch_merge_f32_t<4>(p, st) : launch_merge_f32_t<8>(p, st);     // fp32: head sizes 64 / 128
+  if (dtype == 2) return p.D == 64 ? launch_merge_f32_t<4>(p, st) : (p.D == 256 ? launch_merge_f32_t<16>(p, st) : launch_merge_f32_t<8>(p, st));
   if (dtype == 0) {
     if (p.D == 64) return launch_merge_t<BF16, 2>(p, st);
     if (p.D == 256) return launch_merge_t<BF16, 8>(p, st);

@@ -120,12 +120,15 @@ class HeadShardedCluster:
 class HeadShardedAdaKV:
     """Ada-SnapKV with heads sharded over ranks.  The per-layer budget couples ALL heads
     (flattened top-(H*base), reference pyramidkv_utils.py:712-717), so there is one exchange step: an
-    all-gather of every rank's per-head SORTED score rows ([H/N, L] 16-bit values, 64 KB per head at S=32k);
-    every rank then evaluates the budgets of all H heads and keeps the capacities of its own.  The flat K/V
-    output and its var-len metadata stay local to the rank (its heads only).
+    all-gather of every rank's per-head descending LISTS - [H/N, M] 16-bit values, whatever ``score_sort_fn`` returns as
+    its second result.  The HIP wiring below (``hip_head_sharded_adakv``) hands over each head's ADAPTIVE top-M list
+    (:709-711 already applied, M = min(L, H_total * base) <= 4096 entries = 8 KB per head; complete rows only beyond that);
+    the CPU tests pass complete sorted rows.  Every rank then evaluates the budgets of all H heads from the gathered
+    lists and keeps the capacities of its own.  The flat K/V output and its var-len metadata stay local to the rank (its
+    heads only).
 
-    ``score_sort_fn(q, k) -> (sorted_idx [Hl, L] int32, sorted_val [Hl, L])`` and
-    ``budget_fn(sorted_val_all [H, L]) -> capacities int32 [H]`` and
+    ``score_sort_fn(q, k) -> (sorted_idx [Hl, M] int32, sorted_val [Hl, M])`` and
+    ``budget_fn(sorted_val_all [H, M]) -> capacities int32 [H]`` and
     ``gather_fn(k, v, sorted_idx, cap_local) -> (K_flat, V_flat, head_lens, cu_klen)`` are the local stages
     (HIP ops on a GPU; tests pass oracle stand-ins on CPU)."""
 

@@ -185,7 +185,7 @@ def test_strerror_and_argument_validation_without_gpu(P):
     assert N.lib.pkv_gather_streaming(d, None, 16, 16, 16, None) == -7
     d.k_stride[2] = 128
     d.D = 256
-    assert N.lib.pkv_gather_streaming(d, 16, 16, 16, 16, None) == -5
+    assert N.lib.pkv_gather_streaming(d, None, 16, 16, 16, None) == -7                      # fp32 at head size 256: accepted since round 5
     d.D, d.topk = 128, 5000
     d.S = 8192
     assert N.lib.pkv_compress(d, 16, 16, 16, 16, 16, None, 16, 1 << 30, None) == -5          # fp32 top-k: k <= 4096
@@ -202,7 +202,9 @@ def test_strerror_and_argument_validation_without_gpu(P):
     m.D = 256
     assert N.lib.pkv_merge_workspace_bytes(m) > need64 and mc() == -4
     m.dtype = 2
-    assert mc() == -5                                                   # fp32 merge: head sizes 64 / 128 only (D is 256 here)
+    for i in range(3):
+        m.k_stride[i] = m.v_stride[i] = m.q_stride[i] = 256
+    assert mc() == -4                                                   # fp32 merge at head size 256: accepted since round 5
     m.D = 128
     for i in range(3):
         m.k_stride[i] = m.v_stride[i] = m.q_stride[i] = 128

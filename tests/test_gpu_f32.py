@@ -35,6 +35,7 @@ def P():
     (1, 8, 4, 2048, 64, 16, "maxpool", 7, "mean"),
     (1, 2, 1, 130, 128, 32, None, 1, "sum"),
     (1, 2, 2, 4100, 128, 64, "avgpool", 13, "sum"),
+    (1, 4, 2, 1500, 256, 8, "maxpool", 7, "sum"),                 # head size 256 (round 5)
 ])
 def test_window_scores_f32(P, kind, B, H, G, S, D, w, pool, ks, reduce):
     q, k, _ = make_qkv(B, H, S, D, "fp32", kind, 7 + S)
@@ -117,16 +118,38 @@ def test_pyramidkv_and_streaming_f32(P):
     assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
 
 
-def test_f32_unsupported_entry_points_fail_loudly(P):
-    """fp32 tensors: every policy and the merge take them since round 4; what is left outside the build is head size 256."""
-    q, k, v = (t.to(DEV) for t in make_qkv(1, 2, 512, 256, "fp32", "gauss", 1))
-    with pytest.raises(ValueError):
-        P.SnapKVCluster(window_size=8, max_capacity_prompt=64).update_kv(k, q, v, None, 1)
-    with pytest.raises(ValueError):
-        P.H2OKVCluster(window_size=8, max_capacity_prompt=64).update_kv(k, q, v, None, 1)
+def test_f32_head_size_256_every_policy(P):
+    """fp32 tensors at head size 256 (round 5: the last shape the reference accepts on this path that libpkv refused):
+    SnapKV / H2O / StreamingLLM / Ada-SnapKV end to end - rows are exact copies of what the kernel's own scores select, the
+    scores match the oracle within fp32 summation noise."""
+    B, H, G, S, w, cap = 1, 4, 2, 1200, 8, 72
+    q, kf, vf = make_qkv(B, H, S, 256, "fp32", "gauss", 256)
+    k_un, v_un = kf[:, ::G].contiguous(), vf[:, ::G].contiguous()
+    k_exp, v_exp = k_un.repeat_interleave(G, dim=1), v_un.repeat_interleave(G, dim=1)
+    qd, kd, vd = q.to(DEV), k_un.to(DEV), v_un.to(DEV)
+    for h2o in (False, True):
+        ref = O.h2o_scores(q, k_exp, w) if h2o else O.pool_scores(O.window_scores(q, k_exp, w), "maxpool", 7)
+        got = (P.ops.score_h2o(qd, kd, w, kv_group=G) if h2o else P.ops.score_window(qd, kd, w, "maxpool", 7, kv_group=G)).cpu()
+        assert ((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item() <= SCORE_RTOL
+        cl = (P.H2OKVCluster if h2o else P.SnapKVCluster)(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+        kc, vc = cl.update_kv(kd, qd, vd, None, G)
+        idx = O.topk_canonical(got, cap - w)
+        kr, vr = O.gather_compact(k_exp, v_exp, idx, w)
+        assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+    kc, vc = P.StreamingLLMKVCluster(window_size=w, max_capacity_prompt=cap).update_kv(kd, qd, vd, None, G)
+    kr, vr = O.streamingllm_update_kv(k_exp, q, v_exp, w, cap)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+    kfl, vfl = cl.update_kv(kd, qd, vd)
+    lens = cl.head_lens.cpu().tolist()
+    assert kfl.shape == (sum(lens), 256) and sum(lens) == cl.klen_sum
+    sg = P.ops.score_window(qd, kd, w, "maxpool", 7, "mean", kv_group=G).cpu()
+    order = O.topk_canonical(sg, max(lens) - w)
+    kr, vr, _ = O._flat_gather(k_exp, v_exp, [order[0, h, :lens[h] - w] for h in range(H)], w)
+    assert torch.equal(kfl.cpu(), kr) and torch.equal(vfl.cpu(), vr)
 
 
-@pytest.mark.parametrize("D,G,S", [(128, 1, 900), (64, 2, 1500), (128, 4, 3000)])
+@pytest.mark.parametrize("D,G,S", [(128, 1, 900), (64, 2, 1500), (128, 4, 3000), (256, 2, 1100)])
 def test_merge_f32_vs_oracle(P, D, G, S):
     """LOOK-M pivot merge on fp32 tensors (round 4; reference :119-170 is dtype-generic).  The pivots come from fp32 cosine
     similarities whose summation order the reference does not pin: every dropped row must choose the oracle's kept row or one
