@@ -232,13 +232,19 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             one_step()
-        host_issue[0] = time.perf_counter() - t0          # this rank's host time to ISSUE the timed steps (before any wait)
         barrier()
         el = time.perf_counter() - t0
         if dist is not None and world > 1:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+        # this rank's host time to ISSUE one step (32 calls) into an empty queue - measured on its own: inside the timed loop the
+        # host runs ahead of the device until the hardware queue is full and then waits for it
+        barrier()
+        h0 = time.perf_counter()
+        one_step()
+        host_issue[0] = time.perf_counter() - h0
+        barrier()
         ag_us = None
         if xch is not None:                  # the collective alone: issue + wait, nothing else on the device
             barrier()
@@ -260,7 +266,7 @@ def main():
         Hkv = a.kv_heads // world
     sets = make_sets(B, Hl, S, dt, dev, 1234 + rank, NSETS, Hkv)
     el, one_step, ag_us = timed_leg(B, a.steps, a.warmup, sets)
-    host_us_per_call = host_issue[0] / a.steps / NUM_LAYERS * 1e6
+    host_us_per_call = host_issue[0] / NUM_LAYERS * 1e6
     ms_per_step = el / a.steps * 1e3
     tokens_per_s = B * S * a.steps / el
     # ---- parity of the TIMED path: the step function that was just timed, layers 0 and 31, against the CPU oracle ----
@@ -589,30 +595,70 @@ def gqa_extra(P, N, rl, dt, dev, S, H, ks, steps):
         {k_: v_ for k_, v_ in rows.items() if v_}
 
 
+def _smi_sampler(samples, stop):
+    """rocm-smi power / shader clock of GPU 0 every ~50 ms until stop[0] (what the H2O pair runs at: it sits at the board's power cap)."""
+    import re
+    while not stop[0]:
+        try:
+            r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
+            c = next(iter(json.loads(r.stdout).values()))
+            pw = next((float(v) for k_, v in c.items() if "Power" in k_ and "W" in k_ and re.match(r"^[0-9.]+$", str(v))), None)
+            m = re.search(r"(\d+)Mhz", str(next((v for k_, v in c.items() if k_.startswith("sclk")), "")))
+            samples.append((pw, float(m.group(1)) if m else None))
+        except Exception:       # noqa: BLE001 - no rocm-smi / another output format: the fields stay null
+            samples.append((None, None))
+        time.sleep(0.05)
+
+
 def h2o_extra(P, N, dt, dev, S, H):
     """Extra (not `value`): BASELINE config 3's other policy - the H2O score of all S query rows (pyramidkv_utils.py:544-554),
     the one kernel pair of this path that is bound by the matrix + vector pipes instead of HBM: 2 * 2 * S^2 * D * H flop against
-    the dense bf16 MFMA peak (2.5 PFLOP/s).  Device time of the two passes from events on the dispatches."""
+    the dense bf16 MFMA peak (2.5 PFLOP/s).  Device time of the two passes from events on the dispatches.  `roofline_issue`
+    prices the same time against what actually bounds the pair (profiles/r04/h2o/h2o_account.md): a SIMD issues one vector
+    instruction per 4 cycles and the port is blocked ~0.4 of an MFMA's duration, which puts the floor of the reference's
+    rounding chain at ~34 (pass 1) / ~33 (pass 2) cycles per 64 elements; cycles here = pass time x the shader clock sampled
+    with rocm-smi DURING the passes x 1024 SIMDs / (S^2 H / 64)."""
+    import threading
     (q, k, _), = make_sets(1, H, S, dt, dev, 808, 1)
     for _ in range(2):
         P.ops.score_h2o(q, k, W)
     torch.cuda.synchronize()
+    samples, stop = [], [False]
+    th = threading.Thread(target=_smi_sampler, args=(samples, stop))
+    th.start()
     N.prof_enable(True)
     N.prof_read(reset=True)
-    iters = 5
-    for _ in range(iters):
+    iters = 0
+    t0 = time.perf_counter()
+    while iters < 5 or time.perf_counter() - t0 < 0.6:          # ~0.6 s: a dozen rocm-smi samples under load
         P.ops.score_h2o(q, k, W)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        iters += 1
+    stop[0] = True
+    th.join()
     prof = N.prof_read(reset=True)
     N.prof_enable(False)
     ms = {kk: prof[kk][0] / max(1, prof[kk][1]) for kk in ("h2o_stats", "h2o_colsum")}
     total = ms["h2o_stats"] + ms["h2o_colsum"]
     flop = 2.0 * 2.0 * S * S * D * H
+    pw = [x[0] for x in samples[1:] if x[0]]
+    sc = [x[1] for x in samples[1:] if x[1]]
+    sclk = sum(sc) / len(sc) if sc else None
+    groups = float(S) * S * H / 64.0 / 1024.0                   # 64-element groups per SIMD and pass
+    issue = None
+    if sclk:
+        c1, c2 = (ms[kk] * 1e-3 * sclk * 1e6 / groups for kk in ("h2o_stats", "h2o_colsum"))
+        issue = {"bound": "vector issue + blocked MFMA port", "unit": "cycles per 64 elements and SIMD",
+                 "achieved": {"stats": round(c1, 1), "colsum": round(c2, 1)}, "floor": {"stats": 34.0, "colsum": 33.0},
+                 "frac": round((34.0 + 33.0) / (c1 + c2), 4), "sclk_mhz_during_the_passes": round(sclk),
+                 "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "samples": len(sc)}
     return {"h2o_score_ms": round(total, 3), "stats_ms": round(ms["h2o_stats"], 3), "colsum_ms": round(ms["h2o_colsum"], 3),
             "roofline": {"bound": "mfma", "achieved": round(flop / (total * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flop / (total * 1e-3) / 1e12 / 2500.0, 4)},
-            "note": "[1,%d,%d,128] %s, N(0,1) inputs: the chip runs this pair at its power cap (profiles/r04/h2o/h2o_account.md)"
-                    % (H, S, str(dt).replace("torch.", ""))}
+            "roofline_issue": issue,
+            "note": "[1,%d,%d,128] %s, N(0,1) inputs: the chip runs this pair at its power cap (profiles/r04/h2o/h2o_account.md); "
+                    "round 5: pass 1 takes its exponentials relative to the first key tile's maximum (no key-norm scan; robust to "
+                    "large-norm keys, profiles/r05/h2o_ab.txt)" % (H, S, str(dt).replace("torch.", ""))}
 
 
 def two_stream_extra(P, dt, dev, S, H, ks, steps):

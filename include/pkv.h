@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 #define PKV_VERSION 200 /* 0.2.0: pkv_desc starts with struct_size (the struct can grow without breaking hosts built against an
-                           older header); pkv_ada_select's budget step is one launch; 0.1.2: short Ada-SnapKV candidate lists */
+                           older header); pkv_ada_select's budget step is one launch; host mirrors are uint64 [H] of
+                           self-validating words; fp32 at D = 256; 0.1.2: short Ada-SnapKV candidate lists */
 /* libpkv.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table (plus nothing). */
 #define PKV_API __attribute__((visibility("default")))
 
@@ -196,12 +197,13 @@ PKV_API int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, 
  * min(L, H*base) is the whole row.  scores: dtype [H][scores_stride], rows of length L <= 65536; PKV_F32 rows (L <= 32768;
  * 32-bit keys, four radix levels; ws >= 1024 + 4*H*256*4 + 4*H*4 bytes) are accepted here and nowhere else among the budget
  * entry points - an fp32 `sum()` ratio has no bit-level target (ATen's order depends on the host), see DESIGN.md section 5.  cu_headlens (optional,
- * int32 [H]): inclusive prefix of head_lens (:687).  host_mirror (optional): device-visible PINNED HOST int32 [H+1]: gets the
- * capacities, then host_seq in word H (release, system scope) - the host polls it instead of copy + stream synchronise.
+ * int32 [H]): inclusive prefix of head_lens (:687).  host_mirror (optional): device-visible PINNED HOST uint64 [H], 8-byte
+ * aligned: word h = host_seq << 32 | ran_out << 31 | cap_h, one system-scope store per head (0.2.0; before: int32 [H+1] with a
+ * fence and a flag word) - the host polls until every word carries host_seq instead of copy + stream synchronise.
  * The gather then needs, per head, its first cap_h entries of the canonical order: pkv_topk with k_per_row = head_capacity. */
 PKV_API int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores, int64_t scores_stride, int32_t base_capacity,
                         double floor_ratio, int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens,
-                        int32_t* cu_klen, int32_t* cu_headlens, int32_t* host_mirror, int32_t host_seq, void* ws, size_t ws_bytes,
+                        int32_t* cu_klen, int32_t* cu_headlens, uint64_t* host_mirror, int32_t host_seq, void* ws, size_t ws_bytes,
                         pkv_stream_t stream);
 
 /* Head-sharded Ada-SnapKV: the budget of :712-717 couples ALL heads, so the ranks exchange one
@@ -216,8 +218,8 @@ PKV_API int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t 
  * (d->reduce = PKV_REDUCE_MEAN, :661) -> top-M indices of every head (d->topk = M, canonical order) -> head budgets +
  * var-len metadata.  Ada-SnapKV: given_capacity = NULL, M >= min(S-w, H*base); writes head_capacity, head_lens, cu_klen.
  * Short lists (0.1.2): with a host_mirror, base <= M < min(S-w, H*base) is accepted as well.  The budgets are then exact
- * unless some head's list runs out at the global threshold; the kernel reports that in bit 30 of the mirror's sequence word
- * (word H = host_seq | 0x40000000; host_seq itself must stay below 2^30) and the caller repeats the call with the full M.
+ * unless some head's list runs out at the global threshold; the kernel reports that in bit 31 of every mirror word
+ * (word h = host_seq << 32 | ran_out << 31 | cap_h; host_seq >= 0) and the caller repeats the call with the full M.
  * (A head of a real prompt takes a few base budgets, not H of them: 8 x base entries per head instead of H x base cut the
  * selection from 21 to 16 us at S = 32768, H = 32, base = 120.)
  * HeadKV: given_capacity = device int32 [H] (host-derived, :855), M >= max capacity; writes head_lens, cu_klen only.
@@ -226,9 +228,10 @@ PKV_API int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t 
 PKV_API int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base_capacity, double floor_ratio,
                    int32_t normalize, const int32_t* given_capacity, int32_t* top_idx, int32_t* head_capacity,
                    int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens /* [H] inclusive prefix (:687), may be NULL */,
-                   int32_t* host_mirror /* may be NULL: device-visible PINNED HOST int32 [H+1]; the budget kernel stores the
-                                           capacities there, fences system-wide, then stores host_seq in [H] - the host may
-                                           poll that word instead of copying + synchronising */,
+                   uint64_t* host_mirror /* may be NULL: device-visible PINNED HOST uint64 [H]; the budget kernel stores
+                                            host_seq << 32 | ran_out << 31 | cap_h in word h (whole 64-bit stores, no fence):
+                                            the host polls until every word carries host_seq instead of copying +
+                                            synchronising */,
                    int32_t host_seq, void* ws, size_t ws_bytes, pkv_stream_t stream);
 
 /* Var-len metadata (:682-698) from head_capacity: head_lens[H] = cap_h + w, cu_klen[H+1]

@@ -226,6 +226,20 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
 //   at T (:714-717); ties, capacities (:719), var-len metadata (:682-691) and the host mirror as in ada_final_kernel.
 // Same integers as the three-kernel path (tests compare both with the oracle).
 // ------------------------------------------------------------------------------------------------
+// sum over all scores of a row (:710) from finalize_kernel's per-workgroup fp64 partials, in workgroup order (a fixed order:
+// run-to-run identical); 8 loads in flight
+__device__ __forceinline__ double row_total(const double* part, int np) {
+  double a = 0.0;
+  for (int j0 = 0; j0 < np; j0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[j0 + j < np ? j0 + j : np - 1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a += (j0 + j < np) ? v[j] : 0.0;
+  }
+  return a;
+}
+
 constexpr int ADA_FUSED_MAX_KEYS = 45056;       // 2 B each (88 KB) + two 32 KB counter arrays + ~6 KB of statics inside 160 KB
 
 // tail shared by ada_final_kernel and ada_fused_kernel: thread h < H holds (gt, eq) of head h; every thread of the workgroup calls
@@ -259,19 +273,20 @@ __device__ __forceinline__ void ada_finish(const BudgetParams& p, int gt, int eq
   }
   if (p.host_mirror) {
     // The boundary exposes klen_sum / max_seqlen_k as Python ints (:685-686), i.e. the host needs the capacities (the
-    // reference syncs for the same reason, :718).  They are written straight into pinned host memory, made visible
-    // system-wide, then flagged: the host polls the flag instead of paying a memcpy + a stream synchronise.
-    if (tid < p.H) {
-      __hip_atomic_store(p.host_mirror + tid, cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __threadfence_system();
-    }
+    // reference syncs for the same reason, :718).  They go straight into pinned host memory as SELF-VALIDATING 64-bit words
+    // (round 5): word h = host_seq << 32 | ran_out << 31 | cap_h, one relaxed system-scope store per head.  A 64-bit store
+    // arrives whole, so the host needs no ordering between words: it polls until every word carries the current sequence
+    // number.  No fence and no separate flag word - round 4's capacities + system fence + release flag cost the kernel
+    // two PCIe round trips before it could retire (and before the host saw anything).
     // Short lists (fewer than min(L, H*base) entries per head): the threshold and every count are exact as long as no list
     // is used up at the threshold (counts above it are below the list length, so nothing was cut off).  A head whose whole
-    // list lies at or above the threshold may own more entries than the list shows: reported in bit 30 of the sequence
-    // word, and the caller repeats the call with the full length.
-    const int exhausted = __syncthreads_or(p.short_list && tid < p.H && gt + eq >= p.L);
-    if (tid == 0)
-      __hip_atomic_store(p.host_mirror + p.H, p.host_seq | (exhausted ? 0x40000000 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // list lies at or above the threshold may own more entries than the list shows: reported in bit 31 of every word, and
+    // the caller repeats the call with the full length.
+    const int ran_out = __syncthreads_or(p.short_list && tid < p.H && gt + eq >= p.L);
+    if (tid < p.H) {
+      const unsigned long long wv = ((unsigned long long)(uint32_t)p.host_seq << 32) | (ran_out ? 0x80000000ull : 0ull) | (unsigned long long)(uint32_t)cap;
+      __hip_atomic_store(p.host_mirror + tid, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   if (head_lens && cu_klen) {                     // :684, :689-691: head_lens = cap + w, cu_klen = exclusive prefix + total
     __syncthreads();
@@ -287,7 +302,7 @@ __device__ __forceinline__ void ada_finish(const BudgetParams& p, int gt, int eq
 }
 
 template <typename T>
-__global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, const uint16_t* list, int Lpad, const double* rowsum) {
+__global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, const uint16_t* list, int Lpad, const double* rowsum, int np) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ada_smem[];
   __shared__ __attribute__((aligned(16))) uint32_t hist[256];
   __shared__ int misc[4];
@@ -303,12 +318,6 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, c
   uint32_t* X2 = X1 + TK_CNT_WORDS;
   const uint32_t inc = lane < 32 ? 1u : 65536u;
   const int cslot = lane & 31;
-  // every list and the 16 partial row sums of every head (thread h: head h) in flight together
-  double2 rp[TK_WAVES / 2];
-  if (p.normalize && tid < H) {
-#pragma unroll
-    for (int j = 0; j < TK_WAVES / 2; ++j) rp[j] = reinterpret_cast<const double2*>(rowsum + (int64_t)tid * TK_WAVES)[j];
-  }
   {
     const uint4* src = reinterpret_cast<const uint4*>(list);
     const int nv = nk >> 3;
@@ -321,12 +330,7 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, c
     }
   }
   for (int i = tid; i < 2 * TK_CNT_WORDS; i += TK_THREADS) X1[i] = 0;     // X1 and X2 are adjacent
-  if (p.normalize && tid < H) {                                           // the 16 partials in wave order: a fixed order, run-to-run identical
-    double a = 0.0;
-#pragma unroll
-    for (int j = 0; j < TK_WAVES / 2; ++j) { a += rp[j].x; a += rp[j].y; }
-    s_rs[tid] = a;
-  }
+  if (p.normalize && tid < H) s_rs[tid] = row_total(rowsum + (int64_t)tid * np, np);
   __syncthreads();
   // ---- per head (one wave each): ratio (:710), adaptive keys in place (:711), high-byte histogram ----
 #pragma unroll 1
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, c
 // every dependent LDS access costs ~100 cycles of wall time and the three phases below walked the lists three times).
 // LDS holds the two bank-spread counter arrays only.  12.7 -> see profiles/r05 (H = 32, lists of 512).
 template <typename T, int RH, int TM>
-__global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams p, const uint16_t* list, int Lpad, const double* rowsum) {
+__global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams p, const uint16_t* list, int Lpad, const double* rowsum, int np) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ada_smem[];
   __shared__ __attribute__((aligned(16))) uint32_t hist[256];
   __shared__ int misc[4];
@@ -414,20 +418,10 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
 #pragma unroll
     for (int t = 0; t < TM; ++t) { const int i = lane + 64 * t; key[r][t] = v[i < M ? i : 0]; }
   }
-  double2 rp[TK_WAVES / 2];
-  if (p.normalize && tid < H) {
-#pragma unroll
-    for (int j = 0; j < TK_WAVES / 2; ++j) rp[j] = reinterpret_cast<const double2*>(rowsum + (int64_t)tid * TK_WAVES)[j];
-  }
 #pragma unroll
   for (int j = 0; j < 2 * TK_CNT_WORDS / (4 * TK_THREADS); ++j)           // X1 and X2 are adjacent: 4 x 16 B per thread
     reinterpret_cast<uint4*>(X1)[j * TK_THREADS + tid] = make_uint4(0, 0, 0, 0);
-  if (p.normalize && tid < H) {                                           // the 16 partials in wave order: a fixed order
-    double a = 0.0;
-#pragma unroll
-    for (int j = 0; j < TK_WAVES / 2; ++j) { a += rp[j].x; a += rp[j].y; }
-    s_rs[tid] = a;
-  }
+  if (p.normalize && tid < H) s_rs[tid] = row_total(rowsum + (int64_t)tid * np, np);
   __syncthreads();
   // ---- ratio (:710), adaptive keys (:711), high-byte histogram ----
   float ratio[RH];
@@ -753,20 +747,20 @@ bool ada_fused_fits(int H, int M) {
 }
 
 template <typename T, int RH>
-static hipError_t launch_ada_fused_reg(const BudgetParams& p, const uint16_t* list, int Lpad, const double* rowsum, hipStream_t st) {
+static hipError_t launch_ada_fused_reg(const BudgetParams& p, const uint16_t* list, int Lpad, const double* rowsum, int np, hipStream_t st) {
   auto fn = ada_fused_reg_kernel<T, RH, 8>;
   const size_t lds = (size_t)2 * TK_CNT_WORDS * 4;
   hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fn, dim3(1), dim3(TK_THREADS), lds, st, p, list, Lpad, rowsum);
+  hipLaunchKernelGGL(fn, dim3(1), dim3(TK_THREADS), lds, st, p, list, Lpad, rowsum, np);
   return hipGetLastError();
 }
 
-hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, int Lpad, const double* rowsum, hipStream_t st) {
+hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, int Lpad, const double* rowsum, int np, hipStream_t st) {
   if (p.L <= 512 && p.H <= 32) {          // the short-list shapes: entries in registers (at most 2 heads x 8 entries per lane)
     const uint16_t* l16 = static_cast<const uint16_t*>(list);
-    if (p.H <= 16) return dtype == 0 ? launch_ada_fused_reg<BF16, 1>(p, l16, Lpad, rowsum, st) : launch_ada_fused_reg<F16, 1>(p, l16, Lpad, rowsum, st);
-    return dtype == 0 ? launch_ada_fused_reg<BF16, 2>(p, l16, Lpad, rowsum, st) : launch_ada_fused_reg<F16, 2>(p, l16, Lpad, rowsum, st);
+    if (p.H <= 16) return dtype == 0 ? launch_ada_fused_reg<BF16, 1>(p, l16, Lpad, rowsum, np, st) : launch_ada_fused_reg<F16, 1>(p, l16, Lpad, rowsum, np, st);
+    return dtype == 0 ? launch_ada_fused_reg<BF16, 2>(p, l16, Lpad, rowsum, np, st) : launch_ada_fused_reg<F16, 2>(p, l16, Lpad, rowsum, np, st);
   }
   auto fn = dtype == 0 ? ada_fused_kernel<BF16> : ada_fused_kernel<F16>;
   const size_t lds = (((size_t)p.H * Lpad * 2 + 15) & ~(size_t)15) + (size_t)2 * TK_CNT_WORDS * 4;
@@ -774,7 +768,7 @@ hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, 
     hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(fn, dim3(1), dim3(TK_THREADS), lds, st, p, static_cast<const uint16_t*>(list), Lpad, rowsum);
+  hipLaunchKernelGGL(fn, dim3(1), dim3(TK_THREADS), lds, st, p, static_cast<const uint16_t*>(list), Lpad, rowsum, np);
   return hipGetLastError();
 }
 

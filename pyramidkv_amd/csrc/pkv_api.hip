@@ -170,7 +170,7 @@ WsLayout ws_layout(const pkv_desc* d) {
 }
 
 int do_score_window(const pkv_desc* d, const void* q, const void* k, void* scores, int64_t stride,
-                    char* ws, const WsLayout& L, hipStream_t st, bool want_cmax = false) {
+                    char* ws, const WsLayout& L, hipStream_t st, bool want_cmax = false, double* rowsum_part = nullptr) {
   LogitsParams lp;
   lp.q = q; lp.k = k;
   lp.logits = ws + L.off_logits;
@@ -200,7 +200,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     fp.pool_kind = d->pool_kind;
     fp.pool_kernel = d->pool_kind == PKV_POOL_NONE ? 1 : d->pool_kernel;
     fp.reduce = d->reduce;
-    fp.cmax = nullptr; fp.cmax_stride = 0; fp.trace = nullptr; fp.wgtrace = nullptr;
+    fp.cmax = nullptr; fp.cmax_stride = 0; fp.trace = nullptr; fp.wgtrace = nullptr; fp.rowsum_part = nullptr; fp.rowsum_np = 0;
     ProfScope ps(PKV_K_FINALIZE, st, true);
     hipError_t e = launch_finalize_f32(fp, st);
     return e == hipSuccess ? PKV_OK : hip_fail(e);
@@ -257,6 +257,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   fp.cmax = want_cmax ? ws + L.off_cmax : nullptr; fp.cmax_stride = L.Lp / 8;
   fp.trace = g_topk_trace ? g_topk_trace + 8 : nullptr;
   fp.wgtrace = g_wg_trace;
+  fp.rowsum_part = rowsum_part; fp.rowsum_np = finalize_blocks(d->S, d->window);
   {
     ProfScope ps(PKV_K_FINALIZE, st, true);
     hipError_t e = launch_finalize(d->dtype, fp, st);
@@ -313,10 +314,10 @@ size_t topk_tmp_bytes(int rows, int L, int k) {
 
 int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t stride, const int32_t* kpr,
             int32_t* idx, int64_t idx_stride, hipStream_t st, const void* cmax = nullptr, int64_t cmax_stride = 0,
-            void* tmp = nullptr, size_t tmp_bytes = 0, void* list_out = nullptr, int64_t list_stride = 0, double* rowsum_out = nullptr) {
+            void* tmp = nullptr, size_t tmp_bytes = 0, void* list_out = nullptr, int64_t list_stride = 0) {
   if (L < 1 || k < 1 || k > L || rows < 1) return PKV_ERR_SHAPE;
   TopkParams tp;
-  tp.list_out = list_out; tp.list_stride = list_stride; tp.rowsum_out = rowsum_out;    // Ada-SnapKV hand-over (single-workgroup rows only)
+  tp.list_out = list_out; tp.list_stride = list_stride;                               // Ada-SnapKV hand-over (single-workgroup rows only)
   if (list_out && (dtype == PKV_F32 || !topk_fits(L, k))) return PKV_ERR_UNSUPPORTED;
   tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
   tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace; tp.wgtrace = g_wg_trace; tp.cmax = cmax; tp.cmax_stride = cmax_stride;
@@ -668,7 +669,7 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
 
 int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores, int64_t scores_stride, int32_t base_capacity,
                         double floor_ratio, int32_t normalize, int32_t window, int32_t* head_capacity, int32_t* head_lens,
-                        int32_t* cu_klen, int32_t* cu_headlens, int32_t* host_mirror, int32_t host_seq, void* ws, size_t ws_bytes,
+                        int32_t* cu_klen, int32_t* cu_headlens, uint64_t* host_mirror, int32_t host_seq, void* ws, size_t ws_bytes,
                         pkv_stream_t stream) {
   if (dtype != PKV_BF16 && dtype != PKV_F16 && dtype != PKV_F32) return PKV_ERR_DTYPE;
   if (!scores || !head_capacity || !ws) return PKV_ERR_NULL;
@@ -683,7 +684,7 @@ int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores,
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = ws; bp.list_ws = nullptr; bp.unsorted = 1;
   bp.window = window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
-  bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.short_list = 0; bp.adaptive_out = nullptr;
+  bp.host_mirror = reinterpret_cast<unsigned long long*>(host_mirror); bp.host_seq = host_seq; bp.short_list = 0; bp.adaptive_out = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(PKV_K_BUDGET, st);
   hipError_t e = dtype == PKV_F32 ? launch_budget_f32(bp, st) : launch_budget(dtype, bp, st);
@@ -714,7 +715,7 @@ int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t M, const
 
 int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base_capacity, double floor_ratio,
                    int32_t normalize, const int32_t* given_capacity, int32_t* top_idx, int32_t* head_capacity,
-                   int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens, int32_t* host_mirror, int32_t host_seq,
+                   int32_t* head_lens, int32_t* cu_klen, int32_t* cu_headlens, uint64_t* host_mirror, int32_t host_seq,
                    void* ws, size_t ws_bytes, pkv_stream_t stream) {
   PKV_LOAD_DESC(d, rc_ld);
   int rc = check_desc(d, true);
@@ -722,13 +723,14 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   if (d->B != 1) return PKV_ERR_SHAPE;                     // reference asserts bsz == 1 (:724)
   if (!q || !k || !top_idx || !head_lens || !cu_klen || !ws) return PKV_ERR_NULL;
   if (!given_capacity && !head_capacity) return PKV_ERR_NULL;
-  if (misaligned(q) || misaligned(k) || misaligned(ws)) return PKV_ERR_ALIGN;
+  if (misaligned(q) || misaligned(k) || misaligned(ws) || (reinterpret_cast<uintptr_t>(host_mirror) & 7)) return PKV_ERR_ALIGN;
+  if (host_mirror && host_seq < 0) return PKV_ERR_SHAPE;
   const int L = d->S - d->window, M = d->topk, H = d->H;
   if (!given_capacity) {
     if (H > 256 || base_capacity < 1 || base_capacity > L) return PKV_ERR_SHAPE;
     // M >= min(L, H*base) decides everything (pkv_ada_budget_topm).  A SHORTER list (>= base) is accepted together with a host
-    // mirror: the result is exact unless bit 30 of the mirror's sequence word says that some head's list ran out
-    if (M < std::min<int64_t>(L, (int64_t)H * base_capacity) && (!host_mirror || M < base_capacity || (host_seq & 0x40000000))) return PKV_ERR_SHAPE;
+    // mirror: the result is exact unless bit 31 of the mirror words says that some head's list ran out
+    if (M < std::min<int64_t>(L, (int64_t)H * base_capacity) && (!host_mirror || M < base_capacity)) return PKV_ERR_SHAPE;
     if (M > 65536) return PKV_ERR_UNSUPPORTED;
   }
   WsLayout W = ws_layout(d);
@@ -737,15 +739,17 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   char* w = static_cast<char*>(ws);
   void* scores = w + W.off_scores;
   const bool cm = topk_cmax() != 0;
-  rc = do_score_window(d, q, k, scores, W.Lp, w, W, st, cm);
-  if (rc) return rc;
-  // Round 5: when the lists of all heads fit one workgroup's LDS the selection itself hands the budget step what it needs
-  // (every head's descending list of raw scores + the row sums) and the budgets are ONE single-workgroup launch
+  // Round 5: when the lists of all heads fit one workgroup's LDS the kernels in front hand the budget step what it needs -
+  // finalize the row sums (one fp64 partial per workgroup), the selection every head's descending list of raw scores - and the
+  // budgets are ONE single-workgroup launch
   const int Lpad = (M + 7) & ~7;
-  const bool fused = !given_capacity && ada_fused_fits(H, M) && topk_fits(L, M) && ada_fused() != 0;
-  double* rowsum = reinterpret_cast<double*>(w + W.off_ada + 1024);           // [H][16] doubles inside the (unused) count tables
+  const int np = finalize_blocks(d->S, d->window);
+  const bool fused = !given_capacity && d->dtype != PKV_F32 && ada_fused_fits(H, M) && topk_fits(L, M) && np <= 128 && ada_fused() != 0;
+  double* rowsum = reinterpret_cast<double*>(w + W.off_ada + 1024);           // [H][np] doubles inside the (then unused) count tables
+  rc = do_score_window(d, q, k, scores, W.Lp, w, W, st, cm, fused ? rowsum : nullptr);
+  if (rc) return rc;
   rc = do_topk(d->dtype, H, L, M, scores, W.Lp, nullptr, top_idx, M, st, cm ? w + W.off_cmax : nullptr, W.Lp / 8,
-               w + W.off_tk, W.tk_bytes, fused ? w + W.off_ada_list : nullptr, Lpad, fused ? rowsum : nullptr);
+               w + W.off_tk, W.tk_bytes, fused ? w + W.off_ada_list : nullptr, Lpad);
   if (rc) return rc;
   if (given_capacity) {                                    // HeadKV: capacities come from the host (:855); metadata only
     hipError_t e = launch_ada_metadata(H, d->window, given_capacity, head_lens, cu_klen, st, cu_headlens);
@@ -758,10 +762,10 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   bp.floor_capacity = (int)((double)base_capacity * floor_ratio);
   bp.normalize = normalize; bp.head_capacity = head_capacity; bp.ws = w + W.off_ada; bp.list_ws = w + W.off_ada_list; bp.unsorted = 0;
   bp.window = d->window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
-  bp.host_mirror = host_mirror; bp.host_seq = host_seq; bp.adaptive_out = nullptr;
+  bp.host_mirror = reinterpret_cast<unsigned long long*>(host_mirror); bp.host_seq = host_seq; bp.adaptive_out = nullptr;
   bp.short_list = M < std::min<int64_t>(L, (int64_t)H * base_capacity) ? 1 : 0;
   ProfScope ps(PKV_K_BUDGET, st);
-  hipError_t e = fused ? launch_ada_fused(d->dtype, bp, w + W.off_ada_list, Lpad, rowsum, st) : launch_budget(d->dtype, bp, st);
+  hipError_t e = fused ? launch_ada_fused(d->dtype, bp, w + W.off_ada_list, Lpad, rowsum, np, st) : launch_budget(d->dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }
 

@@ -171,24 +171,21 @@ __device__ __forceinline__ void load_frags(u32x4 (&f)[KS], const uint16_t* base,
 }
 // the 16 MFMAs of one 16-row sub-tile (fragments f, the A operand) against the wave's 64 resident rows (B): four
 // independent accumulators back to back, no dependent-MFMA stall.  D[streamed row][resident row].
-// H2O_SETPRIO (A/B knob, tools/build_h2o_variants.sh; default off): wave priority around the MFMA group.  1 = the wave that is
-// issuing MFMAs outranks the waves in their vector epilogues; 2 = the opposite (the epilogue waves win the issue slots an
-// MFMA leaves free).  Measured in round 5: see profiles/r05/h2o_setprio_ab.txt.
-#ifndef H2O_SETPRIO
-#define H2O_SETPRIO 0
-#endif
-template <typename T, int KS>
+// LOWPRIO: the wave drops to priority 0 while it issues its 16 MFMAs and runs its vector epilogue at priority 1, so the
+// epilogue instructions of the other waves of the SIMD win the issue slots an MFMA leaves free.  Round 5 A/B (complete
+// libraries, same session, profiles/r05/h2o_ab.txt): pass 2 -1.6 % / -1.3 % / -3.0 % at S = 32768 / 8192 / 4096, pass 1
+// -0.4 % / +2.3 % / +3.7 % (its statistics chain is shorter than the MFMA group: nothing to win, and the priority switches cost);
+// the opposite assignment (MFMA waves first) changes nothing.  So pass 2 uses it and pass 1 does not.
+template <typename T, int KS, bool LOWPRIO = false>
 __device__ __forceinline__ void mm16(f32x4 (&acc)[4], const u32x4 (&f)[KS], const u32x4 (&res)[4][KS]) {
 #pragma unroll
   for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (H2O_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
-  if (H2O_SETPRIO == 2) __builtin_amdgcn_s_setprio(0);
+  if (LOWPRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = Mfma2<T>::run(f[kk], res[n][kk], acc[n]);
-  if (H2O_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
-  if (H2O_SETPRIO == 2) __builtin_amdgcn_s_setprio(1);
+  if (LOWPRIO) __builtin_amdgcn_s_setprio(1);
 }
 
 // Pass 1: per query row, c_row = -log2 sum_j exp(x_ij).  Resident = 256 query rows, streamed = K.
@@ -376,7 +373,7 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(H2OParams p) {
       read_frags<KS>(qf, cur, sub, li, lg);
       const f32x4 st = *reinterpret_cast<const f32x4*>(cst + sub * 16 + lg * 4);
       f32x4 accs[4];
-      mm16<T, KS>(accs, qf, kf);                               // D[query][key]
+      mm16<T, KS, true>(accs, qf, kf);                         // D[query][key]
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         float x[4], e[4];

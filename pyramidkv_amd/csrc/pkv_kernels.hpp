@@ -89,6 +89,11 @@ struct FinalizeParams {
   int64_t cmax_stride;
   unsigned long long* trace;   // debug: phase timestamps of block (0,0) (may be null)
   unsigned long long* wgtrace;
+  // Ada-SnapKV (round 5): the sum over ALL pooled scores of a row (:710 `attn_score.sum(dim=-1)`) as one fp64 partial per
+  // workgroup, [B*H][rowsum_np] with rowsum_np = the grid's x dimension (1024 positions each); added in workgroup order by the
+  // budget kernel (a fixed order: run-to-run identical).  May be null.
+  double* rowsum_part;
+  int rowsum_np;
 };
 
 struct TopkParams {
@@ -108,12 +113,11 @@ struct TopkParams {
   int algo;              // small-k fast path: 1 = one-level histogram + bucket counting sort, 0 = two-level select + radix ordering
   int nseg, seg_len;     // long rows: workgroup r handles segment r % nseg (seg_len keys) of row r / nseg and writes
                          // row-global indices to idx_out row r; L stays the full row length.  nseg <= 1: off
-  // Ada-SnapKV (round 5): the selection also hands over what the budget step needs of the row, so that no kernel has to
-  // look the winners' scores up again or re-read the row: the winners' RAW scores in output order (the head's descending
-  // list, :706) and the sum over ALL scores of the row (:710) as 16 per-wave partial sums (added in a fixed order later).
+  // Ada-SnapKV (round 5): the selection also hands over the winners' RAW scores in output order (the head's descending list,
+  // :706), so that the budget step does not look them up again.  (The sum over all scores of the row, :710, comes from
+  // finalize_kernel, which has every score in registers anyway.)
   void* list_out;        // [rows][list_stride] model dtype, or null
   int64_t list_stride;
-  double* rowsum_out;    // [rows][16], or null
 };
 
 struct SortParams {
@@ -162,9 +166,9 @@ struct BudgetParams {
   int32_t* cu_klen_out;      // [H+1] or null
   int32_t* cu_headlens_out;  // [H] inclusive prefix (:687) or null
   void* adaptive_out;        // optional: dtype [H][L] - emit every head's adaptive list (:711) and stop (head-sharded exchange)
-  int32_t* host_mirror;      // optional: device-visible PINNED HOST memory [H+1]; gets the capacities, then host_seq in [H]
+  unsigned long long* host_mirror;   // optional: device-visible PINNED HOST memory, uint64 [H]: word h = host_seq << 32 | ran_out << 31 | cap_h
   int32_t host_seq;
-  int short_list;            // the lists are SHORTER than min(L, H*base): bit 30 of the sequence word reports a head whose list ran out
+  int short_list;            // the lists are SHORTER than min(L, H*base): bit 31 of the mirror words reports a head whose list ran out
   int unsorted;              // 1: `scores` are the un-sorted rows [H][scores_stride] of length Lrow and no list is given
   void* list_ws;             // optional: H * roundup(L,8) * 2 bytes, 16-B aligned - the looked-up lists travel through it
   void* ws;                  // 1024 B ratios + 2 * H*256 int32
@@ -231,10 +235,12 @@ hipError_t launch_aten_small_order(int dtype, int rows, int k, const void* score
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);
 hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
-// Ada-SnapKV budgets + metadata in ONE single-workgroup launch from the lists / row sums topk_kernel left behind (p.L entries
-// per head at list[h * Lpad]); ada_fused_fits() = the lists of all heads fit one workgroup's LDS next to the counters
+// Ada-SnapKV budgets + metadata in ONE single-workgroup launch from the lists topk_kernel left behind (p.L entries per head at
+// list[h * Lpad]) and finalize_kernel's row-sum partials (rowsum[h * np .. + np)); ada_fused_fits() = the lists of all heads fit
+// one workgroup's LDS next to the counters
 bool ada_fused_fits(int H, int M);
-hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, int Lpad, const double* rowsum, hipStream_t st);
+hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, int Lpad, const double* rowsum, int np, hipStream_t st);
+int finalize_blocks(int S, int w);     // workgroups per (b, h) row of finalize_kernel = row-sum partials per head
 hipError_t launch_ada_final(const BudgetParams& p, int32_t* cum_hi, int32_t* cum_lo, const int32_t* above_hi, hipStream_t st);
 hipError_t launch_budget_f32(const BudgetParams& p, hipStream_t st);      // fp32 score rows (pkv_f32.hip), ws: 1024 + 4*H*256*4 + 4*H*4 bytes
 int budget_f32_max_row();

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   __shared__ float rowM[128];           // window <= 128 (check_desc)
   __shared__ float rowS[128];
   __shared__ __attribute__((aligned(16))) float halo_p[2 * FN_HALO * 64];   // rounded probabilities of the halo tasks, [position][window row] (w <= 64 path)
+  __shared__ double rs_red[4];
 
   const int tid = threadIdx.x;
   const int bh = blockIdx.y;
@@ -424,6 +425,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
     const uint32_t bo = __shfl_xor((uint32_t)b4, 1, 64);
     if (writer && !(tid & 1))
       reinterpret_cast<uint16_t*>(p.cmax)[(int64_t)bh * p.cmax_stride + (s0 >> 3)] = (mo > m4) ? (uint16_t)bo : b4;
+  }
+  if (p.rowsum_part) {        // Ada-SnapKV: this workgroup's share of the sum over all scores of the row (:710), fp64
+    double sa = 0.0;
+    if (writer) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (s0 + e < L) sa += (double)Elem<T>::to_f32(res[e]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64);
+    if ((tid & 63) == 0) rs_red[tid >> 6] = sa;
+    __syncthreads();
+    if (tid == 0) p.rowsum_part[(int64_t)bh * p.rowsum_np + blockIdx.x] = ((rs_red[0] + rs_red[1]) + rs_red[2]) + rs_red[3];
   }
   if (!writer) return;
   uint2 ro;
@@ -699,6 +712,8 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
 #undef PKV_LAUNCH
   return hipGetLastError();
 }
+
+int finalize_blocks(int S, int w) { return (S - w + FN_OUT - 1) / FN_OUT; }
 
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st) {
   const int L = p.S - p.w;

@@ -106,10 +106,9 @@ __device__ __forceinline__ void radix_pass(const uint32_t* src, uint32_t* dst, u
   __syncthreads();
 }
 
-// ADA (round 5, pkv_ada_select): the launch also emits, per row, the winners' raw scores in output order (p.list_out) and 16
-// per-wave partial sums over ALL scores of the row (p.rowsum_out) - what Ada-SnapKV's budget step (:709-719) needs of the
-// row - so that no later kernel looks the winners up again or re-reads the 2 MB of score rows.  A template parameter: the
-// plain selection keeps its register budget (120 VGPRs at 4 waves per SIMD).
+// ADA (round 5, pkv_ada_select): the launch also emits, per row, the winners' raw scores in output order (p.list_out) - every
+// head's descending list, what Ada-SnapKV's budget step (:709-719) works on - so that no later kernel looks the winners up
+// again.  A template parameter: the plain selection carries no extra store.
 template <typename T, bool ADA>
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -203,24 +202,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   for (int i = tid; i < TK_CNT_WORDS; i += TK_THREADS) { X[i] = 0; if (dual) X2[i] = 0; }
   __syncthreads();
   if (PKV_TRACE(p) && tid == 0 && row == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PKV_TRACE(p)[7] = (unsigned long long)clock64(); }
-  // ADA: sum over all scores of the row (:710 `attn_score.sum(dim=-1)`), fp64 like ada_stats_kernel: this wave's share goes
-  // out as one partial, the 16 partials are added in wave order by the budget kernel (a fixed order: run-to-run identical).
-  // It needs the WHOLE row in registers, so it runs where the row has arrived anyway: in the small-k path after the threshold
-  // search on the chunk maxima (which arrive first and hide the row's cold round trip), not right behind the loads.
-  auto row_sum = [&]() {
-    double sa = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < niter) {
-        const int base = wave * Lw + j * 512 + lane * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (base + e < L) sa += (double)Elem<T>::to_f32(raw[j].h[e]);
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64);
-    if (lane == 0) p.rowsum_out[(int64_t)vrow * TK_WAVES + wave] = sa;
-  };
   U4 kreg[8];     // this lane's ordered keys (niter chunks of 8), kept in registers for every later pass
   auto transform_all = [&]() {
 #pragma unroll
@@ -238,7 +219,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     }
   };
   const bool fast2 = fast_ok && dual && vec_ok && p.algo == 1;      // one-level fast path, see below
-  if (ADA && !(fast2 && use_cmax)) row_sum();
   if (!use_cmax && !fast2) transform_all();
 
   // ---- one-level fast path (algo 1, small k).  Cost model: 1024 threads on one CU = every wave-instruction costs
@@ -316,7 +296,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       xstar = (cb * 32 + (uint32_t)src2) << 3;
     }
     PKV_STAMP(1);
-    if (ADA && use_cmax) row_sum();
     // stage the passing chunks: one LDS atomic per wave reserves the slots of all its passing chunks
     {
       // (the pass masks are recomputed in the second loop instead of being kept: 8 live 64-bit masks push this kernel over
@@ -843,7 +822,7 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
 }
 
 hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st) {
-  const bool ada = p.list_out != nullptr && p.rowsum_out != nullptr;
+  const bool ada = p.list_out != nullptr;
   auto fn = dtype == 0 ? (ada ? topk_kernel<BF16, true> : topk_kernel<BF16, false>) : (ada ? topk_kernel<F16, true> : topk_kernel<F16, false>);
   if (lds > 64 * 1024) {
     hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);

@@ -445,11 +445,12 @@ def test_adakv_short_list_retry_logic_on_the_host(monkeypatch):
     from pyramidkv_amd import config as cfg
 
     m = object.__new__(U._HostMirror)                 # the real class minus its pinned allocation (no accelerator here)
-    m.np = np.zeros(5, dtype=np.int32); m.t = torch.from_numpy(m.np); m.H, m.seq = 4, 0
-    seq = m.next_seq()
-    m.np[:4] = [3, 9, 1, 7]; m.np[4] = seq | 0x40000000
+    m.np = np.zeros(4, dtype=np.int64); m.t = torch.from_numpy(m.np); m.H, m.seq = 4, 0
+    seq = m.next_seq()                                 # word h = seq << 32 | ran_out << 31 | cap_h
+    m.np[:] = [(seq << 32) | 0x80000000 | c for c in (3, 9, 1, 7)]
     assert m.wait("cpu") == [3, 9, 1, 7] and m.exhausted
-    seq = m.next_seq(); m.np[4] = seq
+    seq = m.next_seq()
+    m.np[:] = [(seq << 32) | c for c in (3, 9, 1, 7)]
     assert m.wait("cpu") == [3, 9, 1, 7] and not m.exhausted
 
     calls = []

@@ -788,11 +788,13 @@ def test_ada_select_one_launch_budgets_equal_the_three_launch_path_and_the_oracl
             for M in sorted({Mfull, min(Mfull, max(512, 2 * base))}):
                 if M > 4096:
                     continue
-                mirror = torch.zeros(H + 1, dtype=torch.int32).pin_memory()
+                mirror = torch.zeros(H, dtype=torch.int64).pin_memory()
                 top, capd, hl, cu, cuh = P.ops.ada_select(qd, kd, w, pool, ks, M, base, floor, norm, host_mirror=mirror, host_seq=7)
                 torch.cuda.synchronize()
-                assert (int(mirror[H]) & 0x3fffffff) == 7
-                ran_out = bool(int(mirror[H]) & 0x40000000)
+                words = mirror.tolist()                  # word h = host_seq << 32 | ran_out << 31 | cap_h
+                assert all((v >> 32) == 7 for v in words)
+                ran_out = bool(words[0] & 0x80000000)
+                assert all(bool(v & 0x80000000) == ran_out for v in words)
                 top3 = P.ops.topk(sg, M)
                 assert torch.equal(top, top3), (ci, norm, M)
                 if M == Mfull:
@@ -801,7 +803,7 @@ def test_ada_select_one_launch_budgets_equal_the_three_launch_path_and_the_oracl
                     assert not ran_out
                 _, caps = O.adakv_head_capacity(sg.cpu()[None], base, floor, norm)
                 if not ran_out:
-                    assert capd.cpu().tolist() == caps[0].tolist() == mirror[:H].tolist(), (ci, norm, M)
+                    assert capd.cpu().tolist() == caps[0].tolist() == [v & 0x7fffffff for v in words], (ci, norm, M)
                     assert hl.cpu().tolist() == [c + w for c in caps[0].tolist()]
                     assert cu.cpu().tolist() == [0] + np.cumsum(hl.cpu().numpy()).tolist() and cuh.cpu().tolist() == cu.cpu().tolist()[1:]
                 else:
