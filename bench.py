@@ -697,6 +697,172 @@ def two_stream_extra(P, dt, dev, S, H, ks, steps):
                     "`one_stream_us_per_update_kv` = the same calls on the same expanded tensors on one stream"}
 
 
+def config2_extra(P, N, rl, alg_bytes, kernel_rows, a, dt, dev, H):
+    """BASELINE config 2 (not `value`): Llama-3-8B shapes, PyramidKV budget 128 at S = 8192 (the reference runners' real
+    LongBench length), all 32 layer budgets through 32 pre-built PyramidKVCluster.update_kv: wall time per call, host time to
+    issue a call, device time per kernel, the K scan against the HBM roofline, and the parity of layers 0 and 31."""
+    S, cap = 8192, 128
+    ks = layer_budgets(P, "pyramidkv", cap, W, S)
+    clusters = make_clusters(P, "pyramidkv", cap)
+    sets = make_sets(1, H, S, dt, dev, 2222, 4)
+    slots = [torch.empty(1, H, ks[layer], dtype=torch.int32, device=dev) for layer in range(NUM_LAYERS)]
+
+    def step(keep=None):
+        for layer in range(NUM_LAYERS):
+            q, k, v = sets[layer % len(sets)]
+            cl = clusters[layer]
+            cl.index_out = slots[layer]
+            kc, vc = cl.update_kv(k, q, v, None, 1)
+            if keep is not None and layer in keep:
+                keep[layer] = (kc, vc, slots[layer].clone())
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    steps = max(5, a.steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    N.prof_enable(True)
+    N.prof_read(reset=True)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    prof = N.prof_read(reset=True)
+    N.prof_enable(False)
+    alg = alg_bytes(1, H, S, sum(ks) / NUM_LAYERS)
+    rows = kernel_rows(prof, alg)
+    call_us = el / steps / NUM_LAYERS * 1e6
+    res = {"workload": "pyramidkv budget=128 window=8 maxpool7, 32 update_kv calls/step, [1,%d,%d,128] %s (expanded K/V)" % (H, S, a.dtype),
+           "update_kv_us": round(call_us, 2), "host_us": round(host / steps / NUM_LAYERS * 1e6, 2),
+           "tokens_per_s": round(S * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
+           "kernels_us": {k_: r["avg_us"] for k_, r in rows.items()},
+           "kernels_sum_us": round(sum(r["avg_us"] for r in rows.values()), 2),
+           "roofline": rows.get("logits"),
+           "call_effective_frac_of_8TBps": round(sum(alg.values()) / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    if not a.no_parity:
+        keep = {0: None, NUM_LAYERS - 1: None}
+        step(keep)
+        torch.cuda.synchronize()
+        res["parity"] = parity_block_for(keep, sets, ks, cap, "pyramidkv", a.dtype, S)
+    del sets
+    torch.cuda.empty_cache()
+    return res
+
+
+def config5_extra(P, N, a, dt, dev):
+    """BASELINE config 5 (not `value`): Mistral-7B attention shapes (32 query heads, 8 KV heads, D = 128), K/V handed over
+    UN-EXPANDED, S = 32768, Ada-SnapKV (floor 0.2, normalize, maxpool-7, window 8) at budget 128 and 2048 through
+    AdaKVCluster.update_kv: wall time per call (the call holds the one host sync of the policy, :718), device time per kernel,
+    what is left for host / sync, the call's algorithmic bytes against the HBM roofline, and a parity block against
+    oracle.adakv_update_kv (the reference's op sequence on the repeat_kv-expanded tensors)."""
+    from oracle import pkv_oracle as O
+    Hq, Hkv, S = 32, 8, 32768
+    g = Hq // Hkv
+    sets = make_sets(1, Hq, S, dt, dev, 5150, 3, Hkv)
+    res = {"workload": "Ada-SnapKV floor=0.2 normalize window=8 maxpool7, q [1,%d,%d,128] + un-expanded K/V [1,%d,%d,128] %s" % (Hq, S, Hkv, S, a.dtype)}
+    for cap in (128, 2048):
+        cl = P.AdaKVCluster(window_size=W, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True,
+                            layer_idx=0, num_hidden_layers=NUM_LAYERS)
+        for it in range(4):
+            q, k, v = sets[it % len(sets)]
+            cl.update_kv(k, q, v)
+        torch.cuda.synchronize()
+        iters = 30
+        t0 = time.perf_counter()
+        for it in range(iters):
+            q, k, v = sets[it % len(sets)]
+            kf, vf = cl.update_kv(k, q, v)
+        torch.cuda.synchronize()
+        call_us = (time.perf_counter() - t0) / iters * 1e6
+        N.prof_enable(True)
+        N.prof_read(reset=True)
+        for it in range(iters):
+            q, k, v = sets[it % len(sets)]
+            cl.update_kv(k, q, v)
+        torch.cuda.synchronize()
+        prof = N.prof_read(reset=True)
+        N.prof_enable(False)
+        kus = {k_: round(v_[0] / v_[1] * 1e3 * (v_[1] / iters), 2) for k_, v_ in prof.items() if v_[1]}      # us per CALL (a kernel may run twice)
+        ksum = sum(kus.values())
+        klen = int(cl.klen_sum)
+        # algorithmic bytes: K once per KV head + the w query rows of every query head (score), pooled scores read once by the
+        # selection, the flat gather 2 tensors x klen_sum rows x D x e x (read + write)
+        alg = Hkv * S * D * E + Hq * W * D * E + Hq * (S - W) * E + 4 * klen * D * E
+        row = {"update_kv_us": round(call_us, 2), "kernels_us_per_call": kus, "kernels_sum_us": round(ksum, 2),
+               "host_sync_remainder_us": round(call_us - ksum, 2), "klen_sum": klen, "max_seqlen_k": int(cl.max_seqlen_k),
+               "list_len": int(getattr(cl, "_list_len", 0)) or None,
+               "tokens_per_s": round(S / call_us * 1e6, 0),
+               "roofline": {"bound": "hbm", "achieved": round(alg / (call_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                            "algorithmic_bytes": int(alg), "what": "whole call (wall time incl. the host sync) over its algorithmic bytes"},
+               "roofline_kernels_only": round(alg / (ksum * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        if not a.no_parity:
+            q, k, v = sets[0]
+            kf, vf = cl.update_kv(k, q, v)
+            torch.cuda.synchronize()
+            qc = q.cpu()
+            kx, vx = (t.cpu().repeat_interleave(g, dim=1) for t in (k, v))
+            torch.set_num_threads(min(os.cpu_count() or 1, 32))
+            with contextlib.redirect_stdout(io.StringIO()):
+                kr, vr, meta = O.adakv_update_kv(kx, qc, vx, W, cap, 7, "maxpool", 0.2, True)
+            lens, rl_ = cl.head_lens.cpu().tolist(), meta.head_lens.tolist()
+            same_lens = lens == rl_
+            heads_kv = 0.0
+            if same_lens:
+                cu = [0] + list(torch.tensor(lens).cumsum(0).tolist())
+                kfc, vfc = kf.cpu(), vf.cpu()
+                heads_kv = sum(bool(torch.equal(kfc[cu[h]:cu[h + 1]], kr[cu[h]:cu[h + 1]]) and torch.equal(vfc[cu[h]:cu[h + 1]], vr[cu[h]:cu[h + 1]]))
+                               for h in range(Hq)) / Hq
+            row["parity"] = {"checker": "oracle.adakv_update_kv on the host CPU (K/V expanded by repeat_kv), same tensors",
+                             "head_budgets_identical": same_lens, "metadata_identical": same_lens and cl.cu_klen.cpu().tolist() == meta.cu_klen.tolist()
+                             and int(cl.klen_sum) == int(meta.klen_sum) and int(cl.max_seqlen_k) == int(meta.max_seqlen_k),
+                             "kv_bit_identical_heads": heads_kv,
+                             "heads_with_other_budget": sum(x != y for x, y in zip(lens, rl_))}
+        res["budget%d" % cap] = row
+    del sets
+    torch.cuda.empty_cache()
+    return res
+
+
+def merge_extra(P, dt, dev, H):
+    """LOOK-M pivot merge (pyramidkv_utils.py:119-170; not `value`): SnapKVCluster(merge="pivot").update_kv next to the plain
+    gather at S = 8192 / 32768, budget 128: wall time per call and the merge step's algorithmic bytes (every K row read once
+    for the cosine pivots + the dropped K and V rows read once for the scatter-mean) against the HBM roofline."""
+    res = {}
+    for S in (8192, 32768):
+        (q, k, v), = make_sets(1, H, S, dt, dev, 31 + S, 1)
+        cap = 128
+        plain = P.SnapKVCluster(window_size=W, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+        merge = P.SnapKVCluster(window_size=W, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool", merge="pivot")
+        idx = P.ops.select(q, k, W, cap - W, "maxpool", 7)
+
+        def timed(fn, iters=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters * 1e3
+        t_plain = timed(lambda: plain.update_kv(k, q, v, None, 1))
+        t_merge = timed(lambda: merge.update_kv(k, q, v, None, 1))
+        t_only = timed(lambda: P.ops.merge_compact(k, v, idx, W))
+        alg = H * S * D * E * 2                      # K rows (pivot search + merge) and V rows (merge), each read once
+        res["S%d_budget%d" % (S, cap)] = {
+            "update_kv_plain_us": round(t_plain, 2), "update_kv_merge_us": round(t_merge, 2), "merge_only_us": round(t_only, 2),
+            "roofline": {"bound": "hbm", "achieved": round(alg / (t_only * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (t_only * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(alg)}}
+        del q, k, v
+        torch.cuda.empty_cache()
+    return res
+
+
 def gpu_eager_baseline(dt, dev, S, H, cap):
     """Same-chip comparator: the reference's eager op sequence - the oracle restatement of
     pyramidkv_utils.py:306-347, ``tensor.topk`` as the reference calls it - executed by PyTorch-ROCm on this GPU on the

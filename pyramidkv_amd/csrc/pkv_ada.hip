@@ -390,7 +390,8 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, c
 }
 
 // The same step for the shapes the short candidate lists produce (H <= 16 * RH heads, lists of at most 64 * TM entries): every
-// lane keeps its entries - entries lane, lane + 64, ... of heads wave, wave + 16 - in REGISTERS from the one global load on
+// lane keeps its entries - entries 8*lane .. 8*lane + 7 of heads wave, wave + 16, ONE 16-byte load per head (2-byte loads: 16 K
+// lane-loads through one CU's address unit, ~2 us) - in REGISTERS from the one global load on
 // (no staging of the lists in LDS, no LDS round trip per entry and phase: a single workgroup runs 16 waves on one CU, where
 // every dependent LDS access costs ~100 cycles of wall time and the three phases below walked the lists three times).
 // LDS holds the two bank-spread counter arrays only.  12.7 -> see profiles/r05 (H = 32, lists of 512).
@@ -410,13 +411,16 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
   const uint32_t inc = lane < 32 ? 1u : 65536u;
   const int cslot = lane & 31;
   // one round trip: this lane's list entries and (thread h: head h) the 16 partial row sums
+  static_assert(TM == 8, "a lane holds ONE 16-byte piece (8 consecutive entries) of every list it owns");
   uint32_t key[RH][TM];
 #pragma unroll
   for (int r = 0; r < RH; ++r) {
     const int h = wave + r * TK_WAVES;
     const uint16_t* v = list + (size_t)(h < H ? h : 0) * Lpad;
+    U4 u;                                                     // entries 8*lane .. 8*lane + 7 (Lpad is a multiple of 8: the piece is inside the row or skipped)
+    u.v = *reinterpret_cast<const uint4*>(v + (8 * lane < Lpad ? 8 * lane : 0));
 #pragma unroll
-    for (int t = 0; t < TM; ++t) { const int i = lane + 64 * t; key[r][t] = v[i < M ? i : 0]; }
+    for (int t = 0; t < TM; ++t) key[r][t] = u.h[t];
   }
 #pragma unroll
   for (int j = 0; j < 2 * TK_CNT_WORDS / (4 * TK_THREADS); ++j)           // X1 and X2 are adjacent: 4 x 16 B per thread
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
     for (int r = 0; r < RH; ++r) {
       st[r] = 0.0;
 #pragma unroll
-      for (int t = 0; t < TM; ++t) if (lane + 64 * t < p.base) st[r] += (double)Elem<T>::to_f32((uint16_t)key[r][t]);
+      for (int t = 0; t < TM; ++t) if (8 * lane + t < p.base) st[r] += (double)Elem<T>::to_f32((uint16_t)key[r][t]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
     for (int t = 0; t < TM; ++t) {
       uint16_t hraw = (uint16_t)key[r][t];
       if (p.normalize) hraw = Elem<T>::from_f32(Elem<T>::to_f32(hraw) * ratio[r]);   // adaptive_attn_score * ratio_weight (:711)
-      const uint32_t k = (hv && lane + 64 * t < M) ? order_key<T>(hraw) : 0u;       // 0 = no entry (real keys are >= 1)
+      const uint32_t k = (hv && 8 * lane + t < M) ? order_key<T>(hraw) : 0u;        // 0 = no entry (real keys are >= 1)
       key[r][t] = k;
       if (k) atomicAdd(&X1[(k >> 8) * 32 + cslot], inc);
     }

@@ -375,16 +375,26 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
             tmpl[dst] = comp[i];
           }
         }
+        if (tid < 4) tmpl[C + tid] = 0u;          // padding behind the list for the 16-byte reads of the ranking (inside X2's spare words)
         __syncthreads();
         PKV_STAMP(5);
-        // HB[d] is now the END of bucket d; rank inside the bucket by comparing composites (unique)
+        // HB[d] is now the END of bucket d; rank inside the bucket by comparing composites (unique).  Four list entries per
+        // LDS read (round 5): the scan starts at the 16-byte boundary at or below the bucket's first entry - whatever lies
+        // between that boundary and the bucket belongs to EARLIER buckets, i.e. larger composites, and is counted exactly as
+        // the `st` entries in front of the bucket were; whatever follows the bucket's end is smaller (or the zero padding
+        // behind the list) and never counted.  Real max-pooled scores put ~30 equal keys into a bucket: this loop was
+        // 6800 of the 25 600 cycles at k = 512 and 1900 of 17 600 at k = 120 (profiles/r05/topk_k_probe_debug.json).
         for (int i = tid; i < (int)C; i += TK_THREADS) {
           const uint32_t mine = tmpl[i];
           const uint32_t db = ((mine >> 16) - xstar) >> SH;
           const uint32_t d = TK2_NB - 1 - (db < (uint32_t)TK2_NB - 1 ? db : (uint32_t)TK2_NB - 1);
           const uint32_t st = d ? HB[d - 1] : 0u, en = HB[d];
-          uint32_t rank = st;
-          for (uint32_t jj = st; jj < en; ++jj) rank += tmpl[jj] > mine;
+          const uint32_t a0 = st & ~3u;
+          uint32_t rank = a0;
+          for (uint32_t jj = a0; jj < en; jj += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tmpl + jj);
+            rank += (uint32_t)(v.x > mine) + (uint32_t)(v.y > mine) + (uint32_t)(v.z > mine) + (uint32_t)(v.w > mine);
+          }
           if (rank < (uint32_t)k) emit((int)rank, mine);
         }
         PKV_STAMP(6);

@@ -506,3 +506,33 @@ def test_adakv_short_list_retry_logic_on_the_host(monkeypatch):
     calls.clear()
     cl2.update_kv(q, q, q)
     assert calls == [1200]                                       # knob off: always the full length
+
+
+def test_no_undefined_global_names_in_the_host_code():
+    """Static check (round 5, after a session lost its bench line to a NameError): every name a function of bench.py,
+    __graft_entry__.py or pyramidkv_amd/*.py reads as a global exists in its module (or is a builtin)."""
+    import builtins
+    import glob
+    import importlib.util
+    import symtable
+    import sys
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(ROOT, "pyramidkv_amd", "*.py")))
+    bad = []
+    for path in files:
+        src = open(path).read()
+        if os.path.dirname(path).endswith("pyramidkv_amd"):
+            mod = importlib.import_module("pyramidkv_amd." + os.path.basename(path)[:-3])
+        else:
+            spec = importlib.util.spec_from_file_location("_chk_" + os.path.basename(path)[:-3], path)
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[spec.name] = mod
+            spec.loader.exec_module(mod)                       # top level only: main() / build() are not called
+
+        def walk(tab):
+            for sym in tab.get_symbols():
+                if sym.is_referenced() and sym.is_global() and not hasattr(mod, sym.get_name()) and not hasattr(builtins, sym.get_name()):
+                    bad.append((os.path.basename(path), tab.get_name(), sym.get_name()))
+            for child in tab.get_children():
+                walk(child)
+        walk(symtable.symtable(src, path, "exec"))
+    assert not bad, bad
