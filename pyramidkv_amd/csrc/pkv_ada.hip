@@ -756,7 +756,7 @@ static hipError_t launch_ada_fused_reg(const BudgetParams& p, const uint16_t* li
   const size_t lds = (size_t)2 * TK_CNT_WORDS * 4;
   hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fn, dim3(1), dim3(TK_THREADS), lds, st, p, list, Lpad, rowsum, np);
+  PKV_KLAUNCH(fn, dim3(1), dim3(TK_THREADS), lds, st, p, list, Lpad, rowsum, np);
   return hipGetLastError();
 }
 
@@ -772,7 +772,7 @@ hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, 
     hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(fn, dim3(1), dim3(TK_THREADS), lds, st, p, static_cast<const uint16_t*>(list), Lpad, rowsum, np);
+  PKV_KLAUNCH(fn, dim3(1), dim3(TK_THREADS), lds, st, p, static_cast<const uint16_t*>(list), Lpad, rowsum, np);
   return hipGetLastError();
 }
 

@@ -764,7 +764,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   bp.window = d->window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
   bp.host_mirror = reinterpret_cast<unsigned long long*>(host_mirror); bp.host_seq = host_seq; bp.adaptive_out = nullptr;
   bp.short_list = M < std::min<int64_t>(L, (int64_t)H * base_capacity) ? 1 : 0;
-  ProfScope ps(PKV_K_BUDGET, st);
+  ProfScope ps(PKV_K_BUDGET, st, fused);            // one launch: its own begin / end (three launches: a bracket of event records)
   hipError_t e = fused ? launch_ada_fused(d->dtype, bp, w + W.off_ada_list, Lpad, rowsum, np, st) : launch_budget(d->dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }
