@@ -356,7 +356,7 @@ class PreparedAda:
     capacities) for fixed shapes and list length M.  ``run`` returns (head_lens, cu_klen, cu_headlens, K_flat, V_flat) with the
     flat outputs sized by ``rows_bound``; the caller narrows them once the capacities are on the host."""
     __slots__ = ("qs", "ks", "vs", "qst", "kst", "vst", "dtype", "device", "dev_index", "H", "M", "D", "dsel", "dsel_ref", "nb",
-                 "dgat", "dgat_ref", "rows_bound", "sizes", "base", "floor", "normalize", "knobs")
+                 "dgat", "dgat_ref", "rows_bound", "sizes", "base", "floor", "normalize", "knobs", "f_sel", "f_gat")
 
     hit = PreparedCompress.hit
 
@@ -372,13 +372,13 @@ class PreparedAda:
         buf = torch.empty(4 * H + 1 + H * M, dtype=torch.int32, device=self.device)     # cap | head_lens | cu_klen | cu_headlens | lists
         p0 = buf.data_ptr()
         p_hl, p_cu, p_cuh, p_top = p0 + 4 * H, p0 + 8 * H, p0 + 4 * (3 * H + 1), p0 + 4 * (4 * H + 1)
-        rc = N.lib.pkv_ada_select(self.dsel_ref, qp, kp, self.base, self.floor, self.normalize, None, p_top, p0, p_hl, p_cu, p_cuh,
-                                  mirror_ptr, seq, ws.data_ptr(), ws.numel(), st)
+        rc = self.f_sel(self.dsel_ref, qp, kp, self.base, self.floor, self.normalize, None, p_top, p0, p_hl, p_cu, p_cuh,
+                        mirror_ptr, seq, ws.data_ptr(), ws.numel(), st)
         if rc:
             N.check(rc, "pkv_ada_select")
         kf = torch.empty((self.rows_bound, self.D), dtype=self.dtype, device=self.device)
         vf = torch.empty((self.rows_bound, self.D), dtype=self.dtype, device=self.device)
-        rc = N.lib.pkv_gather_flat(self.dgat_ref, kp, vp, p_top, M, p0, p_cu, kf.data_ptr(), vf.data_ptr(), self.rows_bound, st)
+        rc = self.f_gat(self.dgat_ref, kp, vp, p_top, M, p0, p_cu, kf.data_ptr(), vf.data_ptr(), self.rows_bound, st)
         if rc:
             N.check(rc, "pkv_gather_flat")
         _, head_lens, cu, cuh, _ = buf.split(self.sizes)          # views for the metadata attributes: after both calls are issued
@@ -408,6 +408,7 @@ def prepare_ada(q, k, v, window: int, pooling, kernel_size: int, M: int, base_ca
     pa.sizes = [H, H, H + 1, H, H * M]
     pa.base, pa.floor, pa.normalize = int(base_capacity), float(floor_ratio), 1 if normalize else 0
     pa.knobs = (_cfg.scale_mode, _cfg.tie_order, _cfg.gqa_dedup)
+    pa.f_sel, pa.f_gat = N.lib.pkv_ada_select, N.lib.pkv_gather_flat
     return pa
 
 

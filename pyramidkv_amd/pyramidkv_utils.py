@@ -329,15 +329,17 @@ class _HostMirror:
         self.seq = self.seq % 0x3fffffff + 1
         return self.seq
 
-    def wait(self, device):
-        """-> the H capacities; ``self.exhausted`` = bit 31 of the words (short lists: some head's list ran out)."""
+    def wait_words(self, device):
+        """-> the H raw words once every one of them carries the current sequence number (word h = seq << 32 | ran_out << 31 |
+        cap_h, so "all carry seq" is one min and one max over the list); ``self.exhausted`` = bit 31."""
         a, last, seq = self.np, self.H - 1, self.seq
+        lo, hi = seq << 32, (seq + 1) << 32
         t_end = time.perf_counter() + 0.5
         spins = 0
         while True:
-            if (int(a[last]) >> 32) == seq:      # the heads' stores leave together: look at one word, then check all of them
+            if lo <= int(a[last]) < hi:          # the heads' stores leave together: look at one word, then check all of them
                 vals = a.tolist()                # copied out before the next call of this instance can reuse the buffer
-                if all((v >> 32) == seq for v in vals):
+                if lo <= min(vals) and max(vals) < hi:
                     break
             spins += 1
             if spins & 63 == 0:
@@ -345,11 +347,15 @@ class _HostMirror:
                 if time.perf_counter() > t_end:  # a lost signal must not hang the host: fall back
                     torch.cuda.current_stream(device).synchronize()
                     vals = a.tolist()
-                    if not all((v >> 32) == seq for v in vals):
+                    if not (lo <= min(vals) and max(vals) < hi):
                         raise RuntimeError("pyramidkv_amd: the budget kernel did not report its head capacities")
                     break
         self.exhausted = bool(vals[0] & 0x80000000)
-        return [v & 0x7fffffff for v in vals]
+        return vals
+
+    def wait(self, device):
+        """-> the H capacities; ``self.exhausted`` = bit 31 of the words (short lists: some head's list ran out)."""
+        return [v & 0x7fffffff for v in self.wait_words(device)]
 
 
 _ADA_TOPM_MAX = 4096      # longest per-head list taken from the top-k kernel; beyond it the rows are sorted completely
@@ -367,6 +373,18 @@ class _FlatPolicy:
         self.cu_headlens = None
 
     _CONST = {}     # (num_heads, device) -> the four read-only index vectors (the decode step only adds cu_offset to cu_klen)
+
+    @property
+    def head_capacity_last(self):
+        """The head capacities of the last update_kv as Python ints (not a reference attribute; tests and the short-list
+        protocol read it).  The fast path keeps the mirror's raw words and decodes them here, on demand."""
+        w = self.__dict__.get("_cap_words")
+        return [v & 0x7fffffff for v in w] if w is not None else self.__dict__.get("_caps")
+
+    @head_capacity_last.setter
+    def head_capacity_last(self, caps):
+        self.__dict__["_cap_words"] = None
+        self.__dict__["_caps"] = caps
 
     def _init_metadata(self, num_heads, head_lens, cu_klen, klen_sum, max_seqlen_k, device, cu_headlens=None):
         self.head_lens = head_lens                                                   # int32 [H]          :684
@@ -466,12 +484,15 @@ class AdaKVCluster(_FlatPolicy):
                 head_lens, cu, cuh, kf, vf = out
                 num_heads, w = pa.H, self.window_size
                 self._init_metadata(num_heads, head_lens, cu, 0, 0, pa.device, cu_headlens=cuh)    # everything but the two host ints
-                caps = mirror.wait(pa.device)
+                words = mirror.wait_words(pa.device)
                 if not (mirror.exhausted and m_use < M):
-                    klen_sum = sum(caps) + num_heads * w
+                    # the words share their upper halves (sequence number, ran-out bit): sum and maximum of the capacities come
+                    # from sum and maximum of the words - between the flag and the return every microsecond is idle GPU
+                    flags = words[0] & ~0x7fffffff
+                    klen_sum = sum(words) - num_heads * flags + num_heads * w
                     self.klen_sum = klen_sum                                             # :685
-                    self.max_seqlen_k = max(caps) + w                                    # :686
-                    self.head_capacity_last = caps
+                    self.max_seqlen_k = (max(words) & 0x7fffffff) + w                    # :686
+                    self._cap_words = words
                     return kf[:klen_sum], vf[:klen_sum]
                 self._fast = None                                    # a list ran out: the general path repeats with the full length
                 self._force_full = True

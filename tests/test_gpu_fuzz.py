@@ -18,7 +18,7 @@ from score_bar import check_h2o_scores, check_window_scores
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-CASES_PER_SEED = 70
+CASES_PER_SEED = 120
 SMAX = 3000
 
 
