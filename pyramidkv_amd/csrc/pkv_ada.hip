@@ -192,6 +192,8 @@ template <int NW>
 __device__ __forceinline__ void ada_finish(const BudgetParams& p, int gt, int eq, float one_minus_floor, int window, int32_t* head_lens,
                                            int32_t* cu_klen, int32_t* cu_headlens, int64_t* s_red, int* s_scan);
 
+__device__ __forceinline__ void ada_finish_wave(const BudgetParams& p, int gt, int eq, int lane);
+
 // Final step, one workgroup: thread h owns head h.  gt_h = entries above the global threshold, eq_h = entries equal to it;
 // the ties are handed out in flattened (head-major) order: head h takes min(eq_h, need - ties taken by the heads before it),
 // an exclusive prefix sum over the heads.  Optionally writes the var-len metadata of :682-691 as well (one launch less).
@@ -209,6 +211,14 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
   if (tid < p.H) {
     gt = b2 < 255 ? ws.cum_lo[tid * 256 + b2 + 1] : (b1 < 255 ? ws.cum_hi[tid * 256 + b1 + 1] : (ws.above_hi ? ws.above_hi[tid] : 0));
     eq = ws.cum_lo[tid * 256 + b2] - gt;
+  }
+  if (p.H <= 64) {                                   // one wave finishes without barriers (find_level above ended with one)
+    if (tid < 64) {
+      BudgetParams q = p;
+      q.one_minus_floor = one_minus_floor; q.window = window; q.head_lens_out = head_lens; q.cu_klen_out = cu_klen; q.cu_headlens_out = cu_headlens;
+      ada_finish_wave(q, gt, eq, tid);
+    }
+    return;
   }
   ada_finish<4>(p, gt, eq, one_minus_floor, window, head_lens, cu_klen, cu_headlens, s_red, s_scan);
 }
@@ -386,6 +396,10 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, c
   }
   __syncthreads();
   const int gt = tid < H ? s_gt[tid] : 0, eq = tid < H ? s_eq[tid] : 0;
+  if (H <= 64) {                                     // one wave finishes without barriers
+    if (wave == 0) ada_finish_wave(p, gt, eq, lane);
+    return;
+  }
   ada_finish<TK_WAVES>(p, gt, eq, p.one_minus_floor, p.window, p.head_lens_out, p.cu_klen_out, p.cu_headlens_out, s_red, s_scan);
 }
 
@@ -395,6 +409,34 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, c
 // (no staging of the lists in LDS, no LDS round trip per entry and phase: a single workgroup runs 16 waves on one CU, where
 // every dependent LDS access costs ~100 cycles of wall time and the three phases below walked the lists three times).
 // LDS holds the two bank-spread counter arrays only.  12.7 -> see profiles/r05 (H = 32, lists of 512).
+// ada_finish for H <= 64 on ONE wave (lane h = head h), no barrier: in the single-workgroup kernels 16 waves would otherwise walk
+// through its ~100 instructions and four barriers for the sake of 32 lanes (4900 of the 25 000 cycles of the one-launch
+// budget kernel, profiles/r05/budget_kernel_stamps.json).
+__device__ __forceinline__ void ada_finish_wave(const BudgetParams& p, int gt, int eq, int lane) {
+  const int64_t total = (int64_t)p.H * p.base;
+  const int64_t need = total - (int64_t)wave_sum_u32((uint32_t)gt);              // sum of gt <= H * L < 2^31
+  const uint32_t incl = wave_incl_scan_u32((uint32_t)eq);
+  const int64_t left = need - ((int64_t)incl - eq);
+  const int take = (int)(left <= 0 ? 0 : (left < eq ? left : eq));
+  const float capf = __fadd_rn(__fmul_rn((float)(gt + take), p.one_minus_floor), (float)p.floor_capacity);   // :719, fp32
+  const int cap = lane < p.H ? (int)rintf(capf) : 0;                                                          // torch.round: half to even
+  if (lane < p.H) p.head_capacity[lane] = cap;
+  if (p.host_mirror) {
+    const bool ran_out = __any(p.short_list && lane < p.H && gt + eq >= p.L) != 0;
+    if (lane < p.H) {
+      const unsigned long long wv = ((unsigned long long)(uint32_t)p.host_seq << 32) | (ran_out ? 0x80000000ull : 0ull) | (unsigned long long)(uint32_t)cap;
+      __hip_atomic_store(p.host_mirror + lane, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (p.head_lens_out && p.cu_klen_out) {            // :684, :689-691
+    const int n = lane < p.H ? cap + p.window : 0;
+    const uint32_t in2 = wave_incl_scan_u32((uint32_t)n);
+    const int off = (int)in2 - n;
+    if (lane < p.H) { p.head_lens_out[lane] = n; p.cu_klen_out[lane] = off; if (p.cu_headlens_out) p.cu_headlens_out[lane] = off + n; }
+    if (lane == p.H - 1) p.cu_klen_out[p.H] = off + n;
+  }
+}
+
 template <typename T, int RH, int TM>
 __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams p, const uint16_t* list, int Lpad, const double* rowsum, int np) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ada_smem[];
@@ -402,10 +444,10 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
   __shared__ int misc[4];
   __shared__ int s_gt[256], s_eq[256];
   __shared__ double s_rs[256];
-  __shared__ int64_t s_red[TK_WAVES];
-  __shared__ int s_scan[TK_WAVES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, M = p.L;
+#define PKV_BSTAMP(i) do { if (PKV_TRACE(p) && tid == 0) PKV_TRACE(p)[i] = (unsigned long long)clock64(); } while (0)
+  PKV_BSTAMP(0);
   uint32_t* X1 = reinterpret_cast<uint32_t*>(ada_smem);
   uint32_t* X2 = X1 + TK_CNT_WORDS;
   const uint32_t inc = lane < 32 ? 1u : 65536u;
@@ -427,6 +469,7 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
     reinterpret_cast<uint4*>(X1)[j * TK_THREADS + tid] = make_uint4(0, 0, 0, 0);
   if (p.normalize && tid < H) s_rs[tid] = row_total(rowsum + (int64_t)tid * np, np);
   __syncthreads();
+  PKV_BSTAMP(1);
   // ---- ratio (:710), adaptive keys (:711), high-byte histogram ----
   float ratio[RH];
   if (p.normalize) {
@@ -464,9 +507,11 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
     }
   }
   __syncthreads();
+  PKV_BSTAMP(2);
   const uint32_t total = (uint32_t)((int64_t)H * p.base);
   select_bin(X1, hist, total, &misc[0], &misc[1], tid);
   __syncthreads();
+  PKV_BSTAMP(3);
   const uint32_t b1 = (uint32_t)misc[0];
   const int above1 = misc[1];
 #pragma unroll
@@ -478,8 +523,10 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
     }
   }
   __syncthreads();
+  PKV_BSTAMP(4);
   select_bin(X2, hist, total - (uint32_t)above1, &misc[2], &misc[3], tid);
   __syncthreads();
+  PKV_BSTAMP(5);
   const uint32_t Tk = (b1 << 8) | (uint32_t)misc[2];
   // ---- per head: entries above / at the threshold ----
 #pragma unroll
@@ -492,8 +539,11 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
     if (lane == 0 && h < H) { s_gt[h] = (int)(packed & 0xffffu); s_eq[h] = (int)(packed >> 16); }
   }
   __syncthreads();
-  const int gt = tid < H ? s_gt[tid] : 0, eq = tid < H ? s_eq[tid] : 0;
-  ada_finish<TK_WAVES>(p, gt, eq, p.one_minus_floor, p.window, p.head_lens_out, p.cu_klen_out, p.cu_headlens_out, s_red, s_scan);
+  PKV_BSTAMP(6);
+  if (wave != 0) return;                             // H <= 32 here: one wave finishes (no barrier below)
+  ada_finish_wave(p, lane < H ? s_gt[lane] : 0, lane < H ? s_eq[lane] : 0, lane);
+  PKV_BSTAMP(7);
+#undef PKV_BSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -627,6 +627,7 @@ int pkv_ada_budget(int32_t dtype, int32_t H, int32_t L, const void* sorted_val, 
   if (H < 1 || H > 256 || L < 1 || base_capacity < 1 || base_capacity > L) return PKV_ERR_SHAPE;
   if (ws_bytes < 1024 + (size_t)2 * H * 256 * 4) return PKV_ERR_WORKSPACE;
   BudgetParams bp;
+  bp.trace = nullptr;
   bp.sorted_idx = nullptr; bp.idx_stride = 0; bp.scores = nullptr; bp.scores_stride = 0; bp.Lrow = L;
   bp.sorted_val = sorted_val; bp.H = H; bp.L = L; bp.base = base_capacity;
   bp.one_minus_floor = (float)(1.0 - floor_ratio);                    // python double, then the fp32 scalar of :719
@@ -654,6 +655,7 @@ int pkv_ada_budget_topm(int32_t dtype, int32_t H, int32_t L, int32_t M, const vo
   if (M > 65536) return PKV_ERR_UNSUPPORTED;          // the staged list must fit in LDS (2 bytes per entry)
   if (ws_bytes < 1024 + (size_t)2 * H * 256 * 4) return PKV_ERR_WORKSPACE;
   BudgetParams bp;
+  bp.trace = nullptr;
   bp.sorted_val = nullptr; bp.sorted_idx = top_idx; bp.idx_stride = idx_stride; bp.scores = scores; bp.scores_stride = scores_stride;
   bp.Lrow = L; bp.H = H; bp.L = M; bp.base = base_capacity;
   bp.one_minus_floor = (float)(1.0 - floor_ratio);
@@ -678,6 +680,7 @@ int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores,
   if (L > (dtype == PKV_F32 ? budget_f32_max_row() : 65536)) return PKV_ERR_UNSUPPORTED;   // a row lives in the registers of one 1024-thread workgroup
   if (ws_bytes < (dtype == PKV_F32 ? 1024 + (size_t)4 * H * 256 * 4 + (size_t)4 * H * 4 : 1024 + (size_t)2 * H * 256 * 4)) return PKV_ERR_WORKSPACE;
   BudgetParams bp;
+  bp.trace = nullptr;
   bp.sorted_val = nullptr; bp.sorted_idx = nullptr; bp.idx_stride = 0; bp.scores = scores; bp.scores_stride = scores_stride;
   bp.Lrow = L; bp.H = H; bp.L = L; bp.base = base_capacity;
   bp.one_minus_floor = (float)(1.0 - floor_ratio);
@@ -701,6 +704,7 @@ int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t M, const
   if (M > 65536) return PKV_ERR_UNSUPPORTED;
   if (ws_bytes < 1024 + (size_t)2 * H * 256 * 4) return PKV_ERR_WORKSPACE;
   BudgetParams bp;
+  bp.trace = nullptr;
   bp.sorted_val = nullptr; bp.sorted_idx = top_idx; bp.idx_stride = idx_stride; bp.scores = scores; bp.scores_stride = scores_stride;
   bp.Lrow = L; bp.H = H; bp.L = M; bp.base = base_capacity;
   bp.one_minus_floor = 1.0f; bp.floor_capacity = 0;
@@ -756,6 +760,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
     return e == hipSuccess ? PKV_OK : hip_fail(e);
   }
   BudgetParams bp;
+  bp.trace = nullptr;
   bp.sorted_val = nullptr; bp.sorted_idx = top_idx; bp.idx_stride = M; bp.scores = scores; bp.scores_stride = W.Lp;
   bp.Lrow = L; bp.H = H; bp.L = M; bp.base = base_capacity;
   bp.one_minus_floor = (float)(1.0 - floor_ratio);
@@ -764,6 +769,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   bp.window = d->window; bp.head_lens_out = head_lens; bp.cu_klen_out = cu_klen; bp.cu_headlens_out = cu_headlens;
   bp.host_mirror = reinterpret_cast<unsigned long long*>(host_mirror); bp.host_seq = host_seq; bp.adaptive_out = nullptr;
   bp.short_list = M < std::min<int64_t>(L, (int64_t)H * base_capacity) ? 1 : 0;
+  bp.trace = g_topk_trace ? g_topk_trace + 16 : nullptr;      // debug build: the caller's buffer holds 32 stamps
   ProfScope ps(PKV_K_BUDGET, st, fused);            // one launch: its own begin / end (three launches: a bracket of event records)
   hipError_t e = fused ? launch_ada_fused(d->dtype, bp, w + W.off_ada_list, Lpad, rowsum, np, st) : launch_budget(d->dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);

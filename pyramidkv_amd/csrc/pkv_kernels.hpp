@@ -172,6 +172,7 @@ struct BudgetParams {
   int unsorted;              // 1: `scores` are the un-sorted rows [H][scores_stride] of length Lrow and no list is given
   void* list_ws;             // optional: H * roundup(L,8) * 2 bytes, 16-B aligned - the looked-up lists travel through it
   void* ws;                  // 1024 B ratios + 2 * H*256 int32
+  unsigned long long* trace; // debug: phase timestamps of the one-launch budget kernel (may be null)
 };
 
 struct MergeParams {         // LOOK-M pivot merge (pkv_merge.hip)

@@ -58,7 +58,7 @@ for _ in range(5):
 torch.cuda.synchronize()
 mirror = cl._mirror
 waits = []
-orig_wait = mirror.wait
+orig_wait = mirror.wait_words            # what the fast path of update_kv calls
 
 
 def timed_wait(device):
@@ -68,7 +68,7 @@ def timed_wait(device):
     return out
 
 
-mirror.wait = timed_wait
+mirror.wait_words = timed_wait
 n = 200
 t0 = time.perf_counter()
 for _ in range(n):
@@ -76,6 +76,6 @@ for _ in range(n):
 torch.cuda.synchronize()
 tot = (time.perf_counter() - t0) / n * 1e6
 res["adakv_S32768_budget128"] = {"update_kv_us": round(tot, 2), "of_which_waiting_for_the_capacities_us": round(sum(waits) / n * 1e6, 2),
-                                 "host_work_us": round(tot - sum(waits) / n * 1e6, 2), "prepared": cl.__dict__.get("_prep") is not None,
-                                 "list_len": cl._prep[1].M if cl.__dict__.get("_prep") else None}
+                                 "host_work_us": round(tot - sum(waits) / n * 1e6, 2), "prepared": cl.__dict__.get("_fast") is not None,
+                                 "list_len": cl._fast[1].M if cl.__dict__.get("_fast") else None}
 print(json.dumps(res, indent=1))

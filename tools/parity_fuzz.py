@@ -95,11 +95,11 @@ while time.time() - t0 < budget:
             cap = w + max(1, min(kk, L // 2))
             tag.update(floor=floor, norm=norm, cap=cap)
             from pyramidkv_amd import config as cfg
-            cfg.ada_short_lists = int(rng.choice([0, 1, 2, 8]))
+            cfg.ada_short_lists = int(rng.choice([0, 1, 2, 4]))
             tag.update(short=cfg.ada_short_lists)
             cl = P.AdaKVCluster(window_size=w, kernel_size=ks, pooling=pool, max_capacity_prompt=cap, floor=floor, normalize=norm)
             kf, vf = cl.update_kv(kd, qd, vd)
-            cfg.ada_short_lists = 8
+            cfg.ada_short_lists = 4
             sg = P.ops.score_window(qd, kd, w, pool, ks, "mean", kv_group=G).cpu()[0]
             sidx, caps = O.adakv_head_capacity(sg[None], cap - w, floor, norm)
             caps = caps[0].tolist()

@@ -33,7 +33,7 @@ for S in (8192, 32768):
             row["candidates"] = t[15]
         res["S%d_k%d" % (S, k)] = row
     # the whole front half of AdaKVCluster.update_kv (score -> top-M + lists + row sums -> one-launch budgets), per kernel
-    mirror = torch.zeros(33, dtype=torch.int32).pin_memory()
+    mirror = torch.zeros(32, dtype=torch.int64).pin_memory()
     for M in (512,):
         for _ in range(3):
             P.ops.ada_select(q, kk, 8, "maxpool", 7, M, 120, 0.2, True, kv_group=4, host_mirror=mirror, host_seq=1)
@@ -43,4 +43,13 @@ for S in (8192, 32768):
         torch.cuda.synchronize()
         pr = N.prof_read(True); N.prof_enable(False)
         res["S%d_ada_select_M%d" % (S, M)] = {k_: round(v_[0] / v_[1] * 1e3, 2) for k_, v_ in pr.items() if v_[1]}
+        if res["debug_build"]:           # phase stamps of the one-launch budget kernel (thread 0): words 16.. of the trace buffer
+            buf = torch.zeros(32, dtype=torch.int64, device="cuda")
+            N.lib.pkv_debug_topk_trace(buf.data_ptr())
+            P.ops.ada_select(q, kk, 8, "maxpool", 7, M, 120, 0.2, True, kv_group=4, host_mirror=mirror, host_seq=1)
+            torch.cuda.synchronize()
+            N.lib.pkv_debug_topk_trace(None)
+            t = buf.cpu().tolist()[16:24]
+            res["S%d_budget_kernel_stamps_rel" % S] = dict(zip(["loads+zero", "ratio+keys+hist1", "select1", "hist2", "select2", "counts", "finish"],
+                                                               [t[i + 1] - t[i] for i in range(7)]))
 print(json.dumps(res, indent=1))
