@@ -350,8 +350,7 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, c
     if (p.normalize) {
       double st = 0.0;
       for (int i = lane; i < p.base; i += 64) st += (double)Elem<T>::to_f32(v[i]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) st += __shfl_xor(st, o, 64);
+      st = wave_sum_f64(st);
       const double a = s_rs[h];
       const float tq = Elem<T>::to_f32(Elem<T>::from_f32((float)st));   // .sum() result in model dtype (:710)
       const float aq = Elem<T>::to_f32(Elem<T>::from_f32((float)a));
@@ -481,10 +480,7 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
       for (int t = 0; t < TM; ++t) if (8 * lane + t < p.base) st[r] += (double)Elem<T>::to_f32((uint16_t)key[r][t]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-      for (int r = 0; r < RH; ++r) st[r] += __shfl_xor(st[r], o, 64);     // the RH reductions run interleaved
-    }
+    for (int r = 0; r < RH; ++r) st[r] = wave_sum_f64(st[r]);
 #pragma unroll
     for (int r = 0; r < RH; ++r) {
       const int h = wave + r * TK_WAVES;

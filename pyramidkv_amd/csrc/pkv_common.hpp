@@ -177,6 +177,29 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }
 
+// wave-wide fp64 sum, broadcast to every lane: the same DPP row shifts / row broadcasts on the two 32-bit halves (12 DPP moves +
+// 6 adds + 2 readlanes; a __shfl_xor butterfly on doubles is 12 ds_bpermute with their address arithmetic, ~85 instructions -
+// half of what the one-launch budget kernel spent on its ratios).  Lanes without a source read +0.0.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#define PKV_DPP_F64_STEP(CTRL, ROWMASK)                                                                                   \
+  do {                                                                                                                   \
+    const unsigned long long b_ = __builtin_bit_cast(unsigned long long, v);                                             \
+    const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b_, CTRL, ROWMASK, 0xf, false);          \
+    const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b_ >> 32), CTRL, ROWMASK, 0xf, false);  \
+    v += __builtin_bit_cast(double, ((unsigned long long)hi_ << 32) | lo_);                                              \
+  } while (0)
+  PKV_DPP_F64_STEP(0x111, 0xf);   // row_shr:1
+  PKV_DPP_F64_STEP(0x112, 0xf);   // row_shr:2
+  PKV_DPP_F64_STEP(0x114, 0xf);   // row_shr:4
+  PKV_DPP_F64_STEP(0x118, 0xf);   // row_shr:8
+  PKV_DPP_F64_STEP(0x142, 0xa);   // row_bcast:15 -> rows 1,3
+  PKV_DPP_F64_STEP(0x143, 0xc);   // row_bcast:31 -> rows 2,3
+#undef PKV_DPP_F64_STEP
+  const unsigned long long t_ = __builtin_bit_cast(unsigned long long, v);
+  const uint32_t tl_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t_, 63), th_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t_ >> 32), 63);
+  return __builtin_bit_cast(double, ((unsigned long long)th_ << 32) | tl_);
+}
+
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: usable with nontemporal builtins
 

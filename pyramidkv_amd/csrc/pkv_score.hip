@@ -432,8 +432,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (s0 + e < L) sa += (double)Elem<T>::to_f32(res[e]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64);
+    sa = wave_sum_f64(sa);
     if ((tid & 63) == 0) rs_red[tid >> 6] = sa;
     __syncthreads();
     if (tid == 0) p.rowsum_part[(int64_t)bh * p.rowsum_np + blockIdx.x] = ((rs_red[0] + rs_red[1]) + rs_red[2]) + rs_red[3];

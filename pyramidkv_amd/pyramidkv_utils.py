@@ -562,7 +562,28 @@ class AdaKVCluster(_FlatPolicy):
             cap, head_lens, cu, cuh = ops.ada_budget_rows(
                 attn_score, self.base_capacity, self.floor_ratio, bool(self.normalize), self.window_size,   # :709-719, :682-691
                 host_mirror=mirror.t if mirror is not None else None, host_seq=mirror.next_seq() if mirror is not None else 0)
-            caps = mirror.wait(key_states.device) if mirror is not None else _read_back(cap)   # the one host sync (:718)
+            # Round 5: selection and flat gather are issued BEFORE the host sync, on the device-resident capacities, with a
+            # guessed upper bound of the largest head capacity (twice the base budget, or twice the largest this layer has seen)
+            # and outputs sized by the bound sum_h cap_h <= H*base + H/2; the read-back then only narrows the views.  Round 4
+            # waited for the capacities first: the GPU idled for the host's round trip in the middle of every call (~10 us of
+            # ~120 at budget 2048).  A capacity beyond the guess (checked after the wait) repeats selection + gather the old way.
+            guess = min(L, max(2 * self.base_capacity, 2 * getattr(self, "_cap_seen", 0)))
+            if mirror is not None and key_states.dtype != torch.float32 and ops.topk_fits(num_heads, L, guess):
+                g = num_heads // key_states.shape[1]
+                bound = num_heads * self.base_capacity + num_heads + num_heads * self.window_size
+                top_idx = ops.topk(attn_score, guess, k_per_row=cap)
+                kf, vf = ops.gather_flat(key_states, value_states, top_idx, cap, cu, self.window_size, bound, max_cap=guess, kv_group=g)
+                caps = mirror.wait(key_states.device)                                    # the one host sync (:718)
+                if max(caps) <= guess:
+                    klen_sum = sum(caps) + num_heads * self.window_size
+                    self._init_metadata(num_heads, head_lens, cu, klen_sum, max(caps) + self.window_size, key_states.device, cu_headlens=cuh)
+                    self.head_capacity_last = caps
+                    if 2 * max(caps) > 2 * self.base_capacity:
+                        self._cap_seen = max(getattr(self, "_cap_seen", 0), max(caps))
+                    return kf[:klen_sum], vf[:klen_sum]
+                self._cap_seen = max(caps)                                               # the guess was too small: the exact path below
+            else:
+                caps = mirror.wait(key_states.device) if mirror is not None else _read_back(cap)   # the one host sync (:718)
             kmax = max(1, max(caps))
             if key_states.dtype == torch.float32 or ops.topk_fits(num_heads, L, kmax):
                 try:
