@@ -225,31 +225,17 @@ __global__ __launch_bounds__(256) void ada_final_kernel(BudgetParams p, AdaWs ws
 
 // ------------------------------------------------------------------------------------------------
 // ada_fused_kernel (round 5): budgets + metadata of pkv_ada_select in ONE single-workgroup launch.
-// topk_kernel<T, true> left every head's descending list of RAW scores (the first L entries of :706's order) and the row
-// sums (:710) behind, H x L <= 45 056 entries: all of it fits the LDS of one 1024-thread workgroup, so the three launches
+// topk_kernel<T, true> left every head's ADAPTIVE list behind (the first L entries of :706's order, times the head's ratio of
+// :710, rounded as in :711, as order-preserving 16-bit keys), H x L <= 45 056 entries: all of it fits the LDS of one
+// 1024-thread workgroup, so the three launches
 // of the list path (ada_stats -> ada_lo -> ada_final, 18.7 us at H = 32: three dependent ~5 us kernels that each wait for
 // the previous one's tables in memory) become one launch without any table in memory and without a device-scope meeting
 // point (the last-block variant of round 4 lost to exactly that fence):
-//   wave w owns heads w, w + 16, ...: sum of the head's `base` largest scores -> ratio (:710) -> the list becomes the list
-//   of ADAPTIVE keys in place (:711) while the high-byte histogram is counted; exact two-level (8+8 bit) radix select of
-//   the (H*base)-th largest adaptive key over all heads (:712-713) = the global threshold T; per head the entries above /
-//   at T (:714-717); ties, capacities (:719), var-len metadata (:682-691) and the host mirror as in ada_final_kernel.
+//   wave w owns heads w, w + 16, ...: exact two-level (8+8 bit) radix select of the (H*base)-th largest adaptive key over
+//   all heads (:712-713) = the global threshold T; per head the entries above / at T (:714-717); ties, capacities (:719),
+//   var-len metadata (:682-691) and the host mirror as in ada_final_kernel (one wave, no barrier, for H <= 64).
 // Same integers as the three-kernel path (tests compare both with the oracle).
 // ------------------------------------------------------------------------------------------------
-// sum over all scores of a row (:710) from finalize_kernel's per-workgroup fp64 partials, in workgroup order (a fixed order:
-// run-to-run identical); 8 loads in flight
-__device__ __forceinline__ double row_total(const double* part, int np) {
-  double a = 0.0;
-  for (int j0 = 0; j0 < np; j0 += 8) {
-    double v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = part[j0 + j < np ? j0 + j : np - 1];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a += (j0 + j < np) ? v[j] : 0.0;
-  }
-  return a;
-}
-
 constexpr int ADA_FUSED_MAX_KEYS = 45056;       // 2 B each (88 KB) + two 32 KB counter arrays + ~6 KB of statics inside 160 KB
 
 // tail shared by ada_final_kernel and ada_fused_kernel: thread h < H holds (gt, eq) of head h; every thread of the workgroup calls
@@ -311,13 +297,11 @@ __device__ __forceinline__ void ada_finish(const BudgetParams& p, int gt, int eq
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, const uint16_t* list, int Lpad, const double* rowsum, int np) {
+__global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, const uint16_t* list, int Lpad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ada_smem[];
   __shared__ __attribute__((aligned(16))) uint32_t hist[256];
   __shared__ int misc[4];
   __shared__ int s_gt[256], s_eq[256];
-  __shared__ double s_rs[256];
   __shared__ int64_t s_red[TK_WAVES];
   __shared__ int s_scan[TK_WAVES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -340,27 +324,12 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_kernel(BudgetParams p, c
     }
   }
   for (int i = tid; i < 2 * TK_CNT_WORDS; i += TK_THREADS) X1[i] = 0;     // X1 and X2 are adjacent
-  if (p.normalize && tid < H) s_rs[tid] = row_total(rowsum + (int64_t)tid * np, np);
   __syncthreads();
-  // ---- per head (one wave each): ratio (:710), adaptive keys in place (:711), high-byte histogram ----
+  // ---- per head (one wave each): high-byte histogram of the adaptive keys (the lists arrive as keys) ----
 #pragma unroll 1
   for (int h = wave; h < H; h += TK_WAVES) {
-    uint16_t* v = keys + (size_t)h * Lpad;
-    float ratio = 1.0f;
-    if (p.normalize) {
-      double st = 0.0;
-      for (int i = lane; i < p.base; i += 64) st += (double)Elem<T>::to_f32(v[i]);
-      st = wave_sum_f64(st);
-      const double a = s_rs[h];
-      const float tq = Elem<T>::to_f32(Elem<T>::from_f32((float)st));   // .sum() result in model dtype (:710)
-      const float aq = Elem<T>::to_f32(Elem<T>::from_f32((float)a));
-      ratio = Elem<T>::to_f32(Elem<T>::from_f32(tq / aq));              // model-dtype division (:710)
-    }
-    for (int i = lane; i < M; i += 64) {
-      const uint32_t key = adaptive_key<T>(v, i, ratio, p.normalize);
-      v[i] = (uint16_t)key;
-      atomicAdd(&X1[(key >> 8) * 32 + cslot], inc);
-    }
+    const uint16_t* v = keys + (size_t)h * Lpad;
+    for (int i = lane; i < M; i += 64) atomicAdd(&X1[((uint32_t)v[i] >> 8) * 32 + cslot], inc);
   }
   __syncthreads();
   const uint32_t total = (uint32_t)((int64_t)H * p.base);            // <= H * M <= 47 104
@@ -436,13 +405,12 @@ __device__ __forceinline__ void ada_finish_wave(const BudgetParams& p, int gt, i
   }
 }
 
-template <typename T, int RH, int TM>
-__global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams p, const uint16_t* list, int Lpad, const double* rowsum, int np) {
+template <int RH, int TM>
+__global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams p, const uint16_t* list, int Lpad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ada_smem[];
   __shared__ __attribute__((aligned(16))) uint32_t hist[256];
   __shared__ int misc[4];
   __shared__ int s_gt[256], s_eq[256];
-  __shared__ double s_rs[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, M = p.L;
 #define PKV_BSTAMP(i) do { if (PKV_TRACE(p) && tid == 0) PKV_TRACE(p)[i] = (unsigned long long)clock64(); } while (0)
@@ -466,40 +434,17 @@ __global__ __launch_bounds__(TK_THREADS) void ada_fused_reg_kernel(BudgetParams 
 #pragma unroll
   for (int j = 0; j < 2 * TK_CNT_WORDS / (4 * TK_THREADS); ++j)           // X1 and X2 are adjacent: 4 x 16 B per thread
     reinterpret_cast<uint4*>(X1)[j * TK_THREADS + tid] = make_uint4(0, 0, 0, 0);
-  if (p.normalize && tid < H) s_rs[tid] = row_total(rowsum + (int64_t)tid * np, np);
   __syncthreads();
   PKV_BSTAMP(1);
-  // ---- ratio (:710), adaptive keys (:711), high-byte histogram ----
-  float ratio[RH];
-  if (p.normalize) {
-    double st[RH];
-#pragma unroll
-    for (int r = 0; r < RH; ++r) {
-      st[r] = 0.0;
-#pragma unroll
-      for (int t = 0; t < TM; ++t) if (8 * lane + t < p.base) st[r] += (double)Elem<T>::to_f32((uint16_t)key[r][t]);
-    }
-#pragma unroll
-    for (int r = 0; r < RH; ++r) st[r] = wave_sum_f64(st[r]);
-#pragma unroll
-    for (int r = 0; r < RH; ++r) {
-      const int h = wave + r * TK_WAVES;
-      const double a = s_rs[h < H ? h : 0];
-      const float tq = Elem<T>::to_f32(Elem<T>::from_f32((float)st[r]));   // .sum() result in model dtype (:710)
-      const float aq = Elem<T>::to_f32(Elem<T>::from_f32((float)a));
-      ratio[r] = Elem<T>::to_f32(Elem<T>::from_f32(tq / aq));              // model-dtype division (:710)
-    }
-  }
+  // ---- high-byte histogram of the adaptive keys (the lists arrive as keys: topk_kernel<T, true>'s epilogue) ----
 #pragma unroll
   for (int r = 0; r < RH; ++r) {
     const bool hv = wave + r * TK_WAVES < H;
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-      uint16_t hraw = (uint16_t)key[r][t];
-      if (p.normalize) hraw = Elem<T>::from_f32(Elem<T>::to_f32(hraw) * ratio[r]);   // adaptive_attn_score * ratio_weight (:711)
-      const uint32_t k = (hv && 8 * lane + t < M) ? order_key<T>(hraw) : 0u;        // 0 = no entry (real keys are >= 1)
-      key[r][t] = k;
-      if (k) atomicAdd(&X1[(k >> 8) * 32 + cslot], inc);
+      const uint32_t kk = (hv && 8 * lane + t < M) ? key[r][t] : 0u;                 // 0 = no entry (real keys are >= 1)
+      key[r][t] = kk;
+      if (kk) atomicAdd(&X1[(kk >> 8) * 32 + cslot], inc);
     }
   }
   __syncthreads();
@@ -796,29 +741,28 @@ bool ada_fused_fits(int H, int M) {
   return H >= 1 && H <= 256 && M >= 1 && (int64_t)H * lpad <= ADA_FUSED_MAX_KEYS;
 }
 
-template <typename T, int RH>
-static hipError_t launch_ada_fused_reg(const BudgetParams& p, const uint16_t* list, int Lpad, const double* rowsum, int np, hipStream_t st) {
-  auto fn = ada_fused_reg_kernel<T, RH, 8>;
+template <int RH>
+static hipError_t launch_ada_fused_reg(const BudgetParams& p, const uint16_t* list, int Lpad, hipStream_t st) {
+  auto fn = ada_fused_reg_kernel<RH, 8>;
   const size_t lds = (size_t)2 * TK_CNT_WORDS * 4;
   hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
   if (e != hipSuccess) return e;
-  PKV_KLAUNCH(fn, dim3(1), dim3(TK_THREADS), lds, st, p, list, Lpad, rowsum, np);
+  PKV_KLAUNCH(fn, dim3(1), dim3(TK_THREADS), lds, st, p, list, Lpad);
   return hipGetLastError();
 }
 
-hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, int Lpad, const double* rowsum, int np, hipStream_t st) {
+hipError_t launch_ada_fused(const BudgetParams& p, const void* list, int Lpad, hipStream_t st) {
   if (p.L <= 512 && p.H <= 32) {          // the short-list shapes: entries in registers (at most 2 heads x 8 entries per lane)
     const uint16_t* l16 = static_cast<const uint16_t*>(list);
-    if (p.H <= 16) return dtype == 0 ? launch_ada_fused_reg<BF16, 1>(p, l16, Lpad, rowsum, np, st) : launch_ada_fused_reg<F16, 1>(p, l16, Lpad, rowsum, np, st);
-    return dtype == 0 ? launch_ada_fused_reg<BF16, 2>(p, l16, Lpad, rowsum, np, st) : launch_ada_fused_reg<F16, 2>(p, l16, Lpad, rowsum, np, st);
+    return p.H <= 16 ? launch_ada_fused_reg<1>(p, l16, Lpad, st) : launch_ada_fused_reg<2>(p, l16, Lpad, st);
   }
-  auto fn = dtype == 0 ? ada_fused_kernel<BF16> : ada_fused_kernel<F16>;
+  auto fn = ada_fused_kernel;
   const size_t lds = (((size_t)p.H * Lpad * 2 + 15) & ~(size_t)15) + (size_t)2 * TK_CNT_WORDS * 4;
   if (lds > 48 * 1024) {
     hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
     if (e != hipSuccess) return e;
   }
-  PKV_KLAUNCH(fn, dim3(1), dim3(TK_THREADS), lds, st, p, static_cast<const uint16_t*>(list), Lpad, rowsum, np);
+  PKV_KLAUNCH(fn, dim3(1), dim3(TK_THREADS), lds, st, p, static_cast<const uint16_t*>(list), Lpad);
   return hipGetLastError();
 }
 

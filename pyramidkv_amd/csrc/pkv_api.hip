@@ -314,10 +314,12 @@ size_t topk_tmp_bytes(int rows, int L, int k) {
 
 int do_topk(int dtype, int rows, int L, int k, const void* scores, int64_t stride, const int32_t* kpr,
             int32_t* idx, int64_t idx_stride, hipStream_t st, const void* cmax = nullptr, int64_t cmax_stride = 0,
-            void* tmp = nullptr, size_t tmp_bytes = 0, void* list_out = nullptr, int64_t list_stride = 0) {
+            void* tmp = nullptr, size_t tmp_bytes = 0, void* list_out = nullptr, int64_t list_stride = 0,
+            const double* rowsum_part = nullptr, int rowsum_np = 0, int ada_base = 0, int ada_normalize = 0) {
   if (L < 1 || k < 1 || k > L || rows < 1) return PKV_ERR_SHAPE;
   TopkParams tp;
   tp.list_out = list_out; tp.list_stride = list_stride;                               // Ada-SnapKV hand-over (single-workgroup rows only)
+  tp.rowsum_part = rowsum_part; tp.rowsum_np = rowsum_np; tp.ada_base = ada_base; tp.ada_normalize = ada_normalize;
   if (list_out && (dtype == PKV_F32 || !topk_fits(L, k))) return PKV_ERR_UNSUPPORTED;
   tp.scores = scores; tp.scores_stride = stride; tp.L = L; tp.k = k; tp.k_per_row = kpr;
   tp.idx_out = idx; tp.idx_stride = idx_stride; tp.trace = g_topk_trace; tp.wgtrace = g_wg_trace; tp.cmax = cmax; tp.cmax_stride = cmax_stride;
@@ -753,7 +755,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   rc = do_score_window(d, q, k, scores, W.Lp, w, W, st, cm, fused ? rowsum : nullptr);
   if (rc) return rc;
   rc = do_topk(d->dtype, H, L, M, scores, W.Lp, nullptr, top_idx, M, st, cm ? w + W.off_cmax : nullptr, W.Lp / 8,
-               w + W.off_tk, W.tk_bytes, fused ? w + W.off_ada_list : nullptr, Lpad);
+               w + W.off_tk, W.tk_bytes, fused ? w + W.off_ada_list : nullptr, Lpad, rowsum, np, base_capacity, normalize ? 1 : 0);
   if (rc) return rc;
   if (given_capacity) {                                    // HeadKV: capacities come from the host (:855); metadata only
     hipError_t e = launch_ada_metadata(H, d->window, given_capacity, head_lens, cu_klen, st, cu_headlens);
@@ -771,7 +773,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   bp.short_list = M < std::min<int64_t>(L, (int64_t)H * base_capacity) ? 1 : 0;
   bp.trace = g_topk_trace ? g_topk_trace + 16 : nullptr;      // debug build: the caller's buffer holds 32 stamps
   ProfScope ps(PKV_K_BUDGET, st, fused);            // one launch: its own begin / end (three launches: a bracket of event records)
-  hipError_t e = fused ? launch_ada_fused(d->dtype, bp, w + W.off_ada_list, Lpad, rowsum, np, st) : launch_budget(d->dtype, bp, st);
+  hipError_t e = fused ? launch_ada_fused(bp, w + W.off_ada_list, Lpad, st) : launch_budget(d->dtype, bp, st);
   return e == hipSuccess ? PKV_OK : hip_fail(e);
 }
 

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
   bool ok[RPT];
   int gi[RPT];
   if (ib) {                                     // uniform branch; the loads inside are unconditional
-    const int last = nsel > 0 ? nsel - 1 : 0;
+    // never past the row of the index list: a capacity beyond the list length (a caller that sized the list by a guess and
+    // checks the capacities afterwards) re-reads the row's last entry instead of running into the next row
+    const int last = min(nsel > 0 ? nsel - 1 : 0, (int)p.idx_stride - 1);
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
       const int r = r_blk + j * SLOTS + slot;

@@ -113,11 +113,16 @@ struct TopkParams {
   int algo;              // small-k fast path: 1 = one-level histogram + bucket counting sort, 0 = two-level select + radix ordering
   int nseg, seg_len;     // long rows: workgroup r handles segment r % nseg (seg_len keys) of row r / nseg and writes
                          // row-global indices to idx_out row r; L stays the full row length.  nseg <= 1: off
-  // Ada-SnapKV (round 5): the selection also hands over the winners' RAW scores in output order (the head's descending list,
-  // :706), so that the budget step does not look them up again.  (The sum over all scores of the row, :710, comes from
-  // finalize_kernel, which has every score in registers anyway.)
-  void* list_out;        // [rows][list_stride] model dtype, or null
+  // Ada-SnapKV (round 5, topk_kernel<T, true>): the selection also hands over every head's ADAPTIVE list (:706-711) as
+  // order-preserving 16-bit keys in output order: the winners' raw scores, times the head's ratio sum(top base) / sum(all)
+  // (:710; the row total comes from finalize_kernel's per-workgroup fp64 partials), rounded to the model dtype (:711).  The
+  // budget step then only has to find the global threshold over those keys.
+  void* list_out;            // [rows][list_stride] uint16 keys, or null
   int64_t list_stride;
+  const double* rowsum_part; // [rows][rowsum_np] finalize_kernel's partial sums of the row (normalize only)
+  int rowsum_np;
+  int ada_base;              // base capacity: the ratio's numerator sums the first ada_base entries of the list
+  int ada_normalize;
 };
 
 struct SortParams {
@@ -236,11 +241,10 @@ hipError_t launch_aten_small_order(int dtype, int rows, int k, const void* score
 hipError_t launch_sort_rows(int dtype, int rows, const SortParams& p, hipStream_t st);
 hipError_t launch_gather(const GatherParams& p, int max_rows, hipStream_t st);
 hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
-// Ada-SnapKV budgets + metadata in ONE single-workgroup launch from the lists topk_kernel left behind (p.L entries per head at
-// list[h * Lpad]) and finalize_kernel's row-sum partials (rowsum[h * np .. + np)); ada_fused_fits() = the lists of all heads fit
-// one workgroup's LDS next to the counters
+// Ada-SnapKV budgets + metadata in ONE single-workgroup launch from the adaptive key lists topk_kernel<T, true> left behind
+// (p.L entries per head at list[h * Lpad]); ada_fused_fits() = the lists of all heads fit one workgroup's LDS next to the counters
 bool ada_fused_fits(int H, int M);
-hipError_t launch_ada_fused(int dtype, const BudgetParams& p, const void* list, int Lpad, const double* rowsum, int np, hipStream_t st);
+hipError_t launch_ada_fused(const BudgetParams& p, const void* list, int Lpad, hipStream_t st);
 int finalize_blocks(int S, int w);     // workgroups per (b, h) row of finalize_kernel = row-sum partials per head
 hipError_t launch_ada_final(const BudgetParams& p, int32_t* cum_hi, int32_t* cum_lo, const int32_t* above_hi, hipStream_t st);
 hipError_t launch_budget_f32(const BudgetParams& p, hipStream_t st);      // fp32 score rows (pkv_f32.hip), ws: 1024 + 4*H*256*4 + 4*H*4 bytes

@@ -106,9 +106,13 @@ __device__ __forceinline__ void radix_pass(const uint32_t* src, uint32_t* dst, u
   __syncthreads();
 }
 
-// ADA (round 5, pkv_ada_select): the launch also emits, per row, the winners' raw scores in output order (p.list_out) - every
-// head's descending list, what Ada-SnapKV's budget step (:709-719) works on - so that no later kernel looks the winners up
-// again.  A template parameter: the plain selection carries no extra store.
+// ADA (round 5, pkv_ada_select): the launch also leaves, per row, the head's ADAPTIVE list behind (p.list_out): the winners'
+// raw scores in output order are emitted with the indices, and an epilogue - one key per thread, on the 32 CUs the heads
+// already occupy - turns them into what Ada-SnapKV's budget step (:709-719) works on: ratio = sum(first `base`) / sum(row)
+// (:710, model-dtype roundings as there; the row total from finalize_kernel's fp64 partials), adaptive = round(raw * ratio)
+// (:711), stored as order-preserving keys.  In the single-workgroup budget kernel the same arithmetic was 390 of 510
+// instructions per wave of its longest phase (16 waves on ONE CU: every instruction costs 16 cycles there).
+// A template parameter: the plain selection carries none of it.
 template <typename T, bool ADA>
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -148,6 +152,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     orow[pos] = seg_off + (int32_t)(0xffffu - (comp & 0xffffu));
     if (ADA) lrow[pos] = key_to_raw<T>(comp >> 16);
   };
+  // ADA: the row total (:710), every wave on its own from finalize_kernel's partials - long before the epilogue needs it
+  double ada_rowsum = 0.0;
+  if (ADA && p.ada_normalize) {
+    const double* part = p.rowsum_part + (int64_t)vrow * p.rowsum_np;
+    for (int j = lane; j < p.rowsum_np; j += 64) ada_rowsum += part[j];
+    ada_rowsum = wave_sum_f64(ada_rowsum);
+  }
   const bool vec_ok = ((p.scores_stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
   const uint32_t inc = lane < 32 ? 1u : 65536u;
   const int cslot = lane & 31;
@@ -216,6 +227,30 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         }
         *reinterpret_cast<uint4*>(keys + base) = kreg[j].v;
       }
+    }
+  };
+  // ADA epilogue (all three selection paths end here): raw scores of the list -> adaptive keys, in place
+  auto ada_epilogue = [&]() {
+    __syncthreads();                                   // every emit of this workgroup is visible to it (one CU, write-through L1)
+    float ratio = 1.0f;
+    if (p.ada_normalize) {
+      double st = 0.0;
+      for (int i = tid; i < p.ada_base && i < k; i += TK_THREADS) st += (double)Elem<T>::to_f32(lrow[i]);
+      st = wave_sum_f64(st);
+      double* red = reinterpret_cast<double*>(hist);   // the histogram scratch is free by now (64-byte aligned)
+      if (lane == 0) red[wave] = st;
+      __syncthreads();
+      double t = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < TK_WAVES; ++w2) t += red[w2];
+      const float tq = Elem<T>::to_f32(Elem<T>::from_f32((float)t));            // .sum() result in model dtype (:710)
+      const float aq = Elem<T>::to_f32(Elem<T>::from_f32((float)ada_rowsum));
+      ratio = Elem<T>::to_f32(Elem<T>::from_f32(tq / aq));                      // model-dtype division (:710)
+    }
+    for (int i = tid; i < k; i += TK_THREADS) {
+      uint16_t h = lrow[i];
+      if (p.ada_normalize) h = Elem<T>::from_f32(Elem<T>::to_f32(h) * ratio);   // adaptive_attn_score * ratio_weight (:711)
+      lrow[i] = (uint16_t)order_key<T>(h);
     }
   };
   const bool fast2 = fast_ok && dual && vec_ok && p.algo == 1;      // one-level fast path, see below
@@ -399,6 +434,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         }
         PKV_STAMP(6);
         if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
+        if (ADA) ada_epilogue();
         return;
       }
     }
@@ -549,6 +585,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       }
       PKV_STAMP(6);
       if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
+      if (ADA) ada_epilogue();
       return;
     }
     // too many keys at or above x* (heavy ties): full path.  Its counters must start from zero.
@@ -714,6 +751,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   }
   PKV_STAMP(6);
   if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
+  if (ADA) ada_epilogue();
 #undef PKV_STAMP
 }
 

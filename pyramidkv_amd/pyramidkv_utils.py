@@ -578,8 +578,6 @@ class AdaKVCluster(_FlatPolicy):
                     klen_sum = sum(caps) + num_heads * self.window_size
                     self._init_metadata(num_heads, head_lens, cu, klen_sum, max(caps) + self.window_size, key_states.device, cu_headlens=cuh)
                     self.head_capacity_last = caps
-                    if 2 * max(caps) > 2 * self.base_capacity:
-                        self._cap_seen = max(getattr(self, "_cap_seen", 0), max(caps))
                     return kf[:klen_sum], vf[:klen_sum]
                 self._cap_seen = max(caps)                                               # the guess was too small: the exact path below
             else:

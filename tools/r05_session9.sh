@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-5 eighth GPU session: the DPP fp64 wave sums (Ada ratios, finalize row sums): Ada / fuzz tests, stamps, benches.
+# Round-5 ninth GPU session: the DPP fp64 wave sums (Ada ratios, finalize row sums): Ada / fuzz tests, stamps, benches.
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/s8
+O=$R/gpurun_out/s9
 rm -rf $O; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_f32.py -m gpu -q --timeout 900 -x -k "fuzz or ada or config5 or headkv or flat" > $O/pytest.txt 2>&1
