@@ -220,8 +220,10 @@ PKV_API int pkv_ada_adaptive_lists(int32_t dtype, int32_t H, int32_t L, int32_t 
  * Short lists (0.1.2): with a host_mirror, base <= M < min(S-w, H*base) is accepted as well.  The budgets are then exact
  * unless some head's list runs out at the global threshold; the kernel reports that in bit 31 of every mirror word
  * (word h = host_seq << 32 | ran_out << 31 | cap_h; host_seq >= 0) and the caller repeats the call with the full M.
- * (A head of a real prompt takes a few base budgets, not H of them: 8 x base entries per head instead of H x base cut the
- * selection from 21 to 16 us at S = 32768, H = 32, base = 120.)
+ * (A head of a real prompt takes a few base budgets, not H of them: max(4 x base, 512) entries per head instead of H x base
+ * cut the selection from 21 to 14 us at S = 32768, H = 32, base = 120.)  With lists that fit one workgroup (H x M <= 45 056)
+ * the budget step is ONE launch: the selection leaves every head's adaptive list behind as 16-bit keys and a single
+ * workgroup selects the global threshold (5 us against 19 us for the three launches of 0.1.x).
  * HeadKV: given_capacity = device int32 [H] (host-derived, :855), M >= max capacity; writes head_lens, cu_klen only.
  * The host then reads the capacities back (klen_sum / max_seqlen_k are Python ints at the boundary, :685-686; the
  * reference has the same sync at :718) and calls pkv_gather_flat(top_idx, idx_stride = M, ...).  ws: pkv_workspace_bytes(d). */
