@@ -562,6 +562,70 @@ def test_cluster_index_out_receives_the_selected_indices(P):
     cl.index_out = None
 
 
+def test_prepared_calls_follow_layout_and_knob_changes(P):
+    """Round 5: a cluster keeps its call prepared per (layouts, budget, knobs) (ops.PreparedCompress / PreparedAda).  Whatever
+    changes between two calls of the SAME cluster - another sequence length, a transposed-view V, un-expanded K/V, another
+    dtype, a mutated attribute, a process-wide knob - the result is the one a fresh cluster gives (bit for bit), and the
+    prepared path is really taken when nothing changes."""
+    from pyramidkv_amd import config as cfg
+    w, cap = 8, 72
+
+    def fresh(cl_kw, k, q, v, g=1):
+        return P.SnapKVCluster(**cl_kw).update_kv(k, q, v, None, g)
+
+    kw = dict(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+    cl = P.SnapKVCluster(**kw)
+    q, k, v = (t.to(DEV) for t in make_qkv(2, 8, 1500, 128, "bf16", "gauss", 501))
+    a = cl.update_kv(k, q, v, None, 1)
+    assert cl._prep is not None
+    hits = []
+    orig_run = P.ops.PreparedCompress.run
+    P.ops.PreparedCompress.run = lambda self, *args, **kws: (hits.append(1), orig_run(self, *args, **kws))[1]
+    try:
+        b = cl.update_kv(k, q, v, None, 1)
+        assert hits and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])             # same layouts: the prepared call
+        vt = v.transpose(1, 2).contiguous().transpose(1, 2)                             # same shape, other strides
+        for kk, qq, vv, g in ((k, q, vt, 1), (k[:, :, :1100], q[:, :, :1100], v[:, :, :1100], 1),
+                              (k[:, ::4].contiguous(), q, v[:, ::4].contiguous(), 1), (k, q, v, 1)):
+            kk, qq = kk.contiguous() if kk.shape[2] != 1500 else kk, qq.contiguous() if qq.shape[2] != 1500 else qq
+            vv = vv.contiguous() if vv.shape[2] != 1500 else vv
+            got, want = cl.update_kv(kk, qq, vv, None, g), fresh(kw, kk, qq, vv, g)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        q16, k16, v16 = (t.to(torch.float16) for t in (q, k, v))                         # another dtype through the same cluster
+        got, want = cl.update_kv(k16, q16, v16, None, 1), fresh(kw, k16, q16, v16)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        cl.window_size, cl.max_capacity_prompt = 16, 100                                 # mutated attributes (the reference's reset())
+        kw2 = dict(kw, window_size=16, max_capacity_prompt=100)
+        got, want = cl.update_kv(k, q, v, None, 1), fresh(kw2, k, q, v)
+        assert got[0].shape[2] == 100 and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        old = cfg.scale_mode
+        try:
+            cfg.scale_mode = "rcp"                                                       # a process-wide knob
+            n0 = len(hits)
+            got = cl.update_kv(k16, q16, v16, None, 1)
+            want = P.ops.compress(q16, k16, v16, 16, 84, "maxpool", 7, scale_mode="rcp")
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        finally:
+            cfg.scale_mode = old
+    finally:
+        P.ops.PreparedCompress.run = orig_run
+    # Ada-SnapKV: the fast path at the top of update_kv follows a changed floor and a changed prompt length
+    qa, ka, va = (t.to(DEV) for t in make_qkv(1, 8, 3000, 128, "bf16", "gauss", 502))
+    akw = dict(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+    ac = P.AdaKVCluster(**akw)
+    r1 = ac.update_kv(ka, qa, va)
+    r2 = ac.update_kv(ka, qa, va)
+    assert ac.__dict__.get("_fast") is not None and torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+    ac.floor_ratio, ac.floor_capacity = 0.5, int(ac.base_capacity * 0.5)
+    r3 = ac.update_kv(ka, qa, va)
+    f3 = P.AdaKVCluster(**dict(akw, floor=0.5))
+    w3 = f3.update_kv(ka, qa, va)
+    assert torch.equal(r3[0], w3[0]) and torch.equal(r3[1], w3[1]) and ac.head_lens.tolist() == f3.head_lens.tolist()
+    r4 = ac.update_kv(ka[:, :, :2000].contiguous(), qa[:, :, :2000].contiguous(), va[:, :, :2000].contiguous())
+    w4 = P.AdaKVCluster(**dict(akw, floor=0.5)).update_kv(ka[:, :, :2000].contiguous(), qa[:, :, :2000].contiguous(), va[:, :, :2000].contiguous())
+    assert torch.equal(r4[0], w4[0]) and torch.equal(r4[1], w4[1])
+
+
 def test_budget_beyond_one_topk_workgroup_takes_the_full_sort(P):
     """Budgets above 16 384 past tokens (nothing the runners use; the reference takes any k <= L): the selection list no longer
     fits one top-k workgroup next to the row, so the host takes the first k entries of the complete canonical order
