@@ -507,7 +507,17 @@ class AdaKVCluster(_FlatPolicy):
         # budgets AND hold every index the gather takes (cap_h <= M).  They come from the top-k kernel (no full sort);
         # score -> top-M -> budgets -> metadata is ONE C call.
         M = min(L, num_heads * self.base_capacity)
-        if M <= _ADA_TOPM_MAX and key_states.dtype != torch.float32:      # fp32 tensors take the un-sorted-rows path below
+        # The list path serves lists up to _ADA_TOPM_MAX entries.  M itself fits for small budgets (H*base <= 4096); for large ones
+        # (budget 2048: M is the whole row) it still applies with SHORT lists of 2 x base entries per head (round 5) - a head of a
+        # real prompt stays below twice its base budget - and a list that runs out sends this layer to the un-sorted-rows
+        # path below for good (there is no longer list to repeat with).
+        full_ok = M <= _ADA_TOPM_MAX
+        short_big = (not full_ok and _cfg.host_poll and _cfg.ada_short_lists > 0 and 2 * self.base_capacity <= _ADA_TOPM_MAX
+                     and not self.__dict__.get("_lists_off"))
+        ran_out = self.__dict__.pop("_force_full", False)                # the fast path above saw a list run out
+        if ran_out and not full_ok:
+            self._lists_off, short_big = True, False
+        if (full_ok or short_big) and key_states.dtype != torch.float32:      # fp32 tensors take the un-sorted-rows path below
             if self.pooling not in ('avgpool', 'maxpool'):
                 raise ValueError('Pooling method not supported')
             mirror = None
@@ -520,12 +530,15 @@ class AdaKVCluster(_FlatPolicy):
             # are exact unless the kernel reports a head whose list ran out (the threshold sits below the list's last entry);
             # then the call is repeated with the full M, and the cluster - one per layer, :1049 - remembers twice the largest
             # share it has seen from then on.
+            def short_len():
+                if not full_ok:
+                    return max(2 * self.base_capacity, 512)
+                return min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity, 512))
             m_use = M
             if mirror is not None and _cfg.ada_short_lists > 0:
-                m_use = min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity, 512))
+                m_use = short_len()
             bound = num_heads * self.base_capacity + num_heads + num_heads * self.window_size
             gq = _unexpanded_group(key_states, query_states)
-            ran_out = self.__dict__.pop("_force_full", False)            # the fast path above saw a list run out
             if ran_out:
                 m_use = M
             while True:
@@ -539,12 +552,14 @@ class AdaKVCluster(_FlatPolicy):
                     if ran_out:      # remembered from now on: this layer's heads want longer lists than the default
                         self._list_len = max(getattr(self, "_list_len", 0), min(M, 2 * max(self.head_capacity_last)))
                     if mirror is not None:                           # the next call with these layouts takes the fast path above
-                        m_next = min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity, 512)) \
-                            if _cfg.ada_short_lists > 0 else M
+                        m_next = short_len() if _cfg.ada_short_lists > 0 else M
                         pa = ops.prepare_ada(query_states, key_states, value_states, self.window_size, self.pooling, self.kernel_size,
                                              m_next, self.base_capacity, self.floor_ratio, bool(self.normalize), _cfg.scale_mode, gq, bound)
                         self._fast = (self._fast_sig(), pa, mirror, m_next, M) if pa is not None else None
                     return out
+                if not full_ok:                                      # large budget: no longer list exists - the un-sorted rows from now on
+                    self._lists_off = True
+                    break
                 ran_out, m_use = True, M
         # H*base > 4096 (budget 2048: M is the whole row, a top-M list would be a full sort).  What :706-719 consume of the
         # order are selections and counts: the budgets come from histograms over the un-sorted rows (pkv_ada_budget_rows),

@@ -742,16 +742,41 @@ def test_adakv_large_budget_without_the_sort(P):
     4096 takes the same per-head top-k."""
     H, S, w, cap = 8, 8192, 8, 1032                      # H * base = 8192
     q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 64)
-    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2,
-                        normalize=True, layer_idx=0, num_hidden_layers=32)
-    kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
     sg = P.ops.score_window(q.to(DEV), k.to(DEV), w, "maxpool", 7, "mean").cpu()[0]
     sidx, caps = O.adakv_head_capacity(sg[None], cap - w, 0.2, True)
     caps = caps[0].tolist()
-    assert cl.head_lens.cpu().tolist() == [c + w for c in caps]
-    assert int(cl.klen_sum) == sum(caps) + H * w == kf.shape[0] and cl.max_seqlen_k == max(caps) + w
     kr, vr, _ = O._flat_gather(k, v, [sidx[0, h, :caps[h]] for h in range(H)], w)
-    assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr)
+    # round 5: large budgets first try SHORT lists of 2 x base entries per head through the list path (exact unless a list runs
+    # out); `_lists_off` is what a run-out leaves behind: the un-sorted-rows path of round 3.  Both give the oracle's bytes,
+    # also on the second call of the same cluster (prepared path / selection issued before the host sync).
+    for lists_off in (False, True):
+        cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2,
+                            normalize=True, layer_idx=0, num_hidden_layers=32)
+        if lists_off:
+            cl._lists_off = True
+        for _ in range(2):
+            kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
+            assert cl.head_lens.cpu().tolist() == [c + w for c in caps], lists_off
+            assert int(cl.klen_sum) == sum(caps) + H * w == kf.shape[0] and cl.max_seqlen_k == max(caps) + w
+            assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr), lists_off
+        assert bool(cl.__dict__.get("_lists_off")) == lists_off
+    # one head that takes more than twice its base budget: the short lists run out, the call falls back by itself
+    k2 = k.clone()
+    k2[0, 3, 500:4000] += 0.9 * q[0, 3, -1]
+    sg2 = P.ops.score_window(q.to(DEV), k2.to(DEV), w, "maxpool", 7, "mean").cpu()[0]
+    sidx2, caps2 = O.adakv_head_capacity(sg2[None], cap - w, 0.2, True)
+    caps2 = caps2[0].tolist()
+    assert max(caps2) > 2 * (cap - w)
+    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
+    for _ in range(2):
+        kf2, vf2 = cl.update_kv(k2.to(DEV), q.to(DEV), v.to(DEV))
+        kr2_, vr2_, _ = O._flat_gather(k2, v, [sidx2[0, h, :caps2[h]] for h in range(H)], w)
+        assert cl.head_lens.cpu().tolist() == [c + w for c in caps2]
+        assert torch.equal(kf2.cpu(), kr2_) and torch.equal(vf2.cpu(), vr2_)
+    assert cl._lists_off
+    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2,
+                        normalize=True, layer_idx=0, num_hidden_layers=32)
+    kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
     kr2, vr2, meta = O.adakv_update_kv(k, q, v, w, cap, 7, "maxpool", 0.2, True)      # end to end (the oracle's own scores)
     _report("adakv_large_budget/S8192cap1032", dict(head_lens_identical=cl.head_lens.cpu().tolist() == meta.head_lens.tolist(),
                                                    kv_identical=bool(torch.equal(kf.cpu(), kr2) and torch.equal(vf.cpu(), vr2))))
