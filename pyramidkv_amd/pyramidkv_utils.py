@@ -531,8 +531,8 @@ class AdaKVCluster(_FlatPolicy):
             # then the call is repeated with the full M, and the cluster - one per layer, :1049 - remembers twice the largest
             # share it has seen from then on.
             def short_len():
-                if not full_ok:
-                    return max(2 * self.base_capacity, 512)
+                if not full_ok:          # large budgets: 2.5 x base, what the list path can hold at most
+                    return min(_ADA_TOPM_MAX, max(2 * self.base_capacity, (5 * self.base_capacity) // 2, 512))
                 return min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity, 512))
             m_use = M
             if mirror is not None and _cfg.ada_short_lists > 0:

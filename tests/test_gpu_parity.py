@@ -761,12 +761,16 @@ def test_adakv_large_budget_without_the_sort(P):
             assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr), lists_off
         assert bool(cl.__dict__.get("_lists_off")) == lists_off
     # one head that takes more than twice its base budget: the short lists run out, the call falls back by itself
-    k2 = k.clone()
-    k2[0, 3, 500:4000] += 0.9 * q[0, 3, -1]
-    sg2 = P.ops.score_window(q.to(DEV), k2.to(DEV), w, "maxpool", 7, "mean").cpu()[0]
-    sidx2, caps2 = O.adakv_head_capacity(sg2[None], cap - w, 0.2, True)
-    caps2 = caps2[0].tolist()
-    assert max(caps2) > 2 * (cap - w)
+    m_short = min(4096, (5 * (cap - w)) // 2)
+    for span, gain in ((4000, 0.9), (6000, 1.5), (7000, 2.5), (8000, 4.0)):
+        k2 = k.clone()
+        k2[0, 3, 100:span] += gain * q[0, 3, -1]
+        sg2 = P.ops.score_window(q.to(DEV), k2.to(DEV), w, "maxpool", 7, "mean").cpu()[0]
+        sidx2, caps2 = O.adakv_head_capacity(sg2[None], cap - w, 0.2, True)
+        caps2 = caps2[0].tolist()
+        if (max(caps2) - int((cap - w) * 0.2)) / 0.8 > m_short + 64:      # the head's share of the global top-(H*base) is beyond the short list
+            break
+    assert (max(caps2) - int((cap - w) * 0.2)) / 0.8 > m_short + 64, caps2
     cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True)
     for _ in range(2):
         kf2, vf2 = cl.update_kv(k2.to(DEV), q.to(DEV), v.to(DEV))
