@@ -360,7 +360,9 @@ class PreparedAda:
 
     hit = PreparedCompress.hit
 
-    def run(self, q, k, v, mirror_ptr, seq):
+    def run(self, q, k, v, mirror_ptr, seq, given_ptr=None):
+        """``given_ptr`` (HeadKV): device int32 [H] of host-derived capacities - no budgets are computed, ``rows_bound`` is then the
+        exact number of output rows."""
         qp, kp, vp = q.data_ptr(), k.data_ptr(), v.data_ptr()
         if (qp | kp | vp) & 15:
             return None
@@ -372,13 +374,14 @@ class PreparedAda:
         buf = torch.empty(4 * H + 1 + H * M, dtype=torch.int32, device=self.device)     # cap | head_lens | cu_klen | cu_headlens | lists
         p0 = buf.data_ptr()
         p_hl, p_cu, p_cuh, p_top = p0 + 4 * H, p0 + 8 * H, p0 + 4 * (3 * H + 1), p0 + 4 * (4 * H + 1)
-        rc = self.f_sel(self.dsel_ref, qp, kp, self.base, self.floor, self.normalize, None, p_top, p0, p_hl, p_cu, p_cuh,
+        rc = self.f_sel(self.dsel_ref, qp, kp, self.base, self.floor, self.normalize, given_ptr, p_top, p0, p_hl, p_cu, p_cuh,
                         mirror_ptr, seq, ws.data_ptr(), ws.numel(), st)
         if rc:
             N.check(rc, "pkv_ada_select")
         kf = torch.empty((self.rows_bound, self.D), dtype=self.dtype, device=self.device)
         vf = torch.empty((self.rows_bound, self.D), dtype=self.dtype, device=self.device)
-        rc = self.f_gat(self.dgat_ref, kp, vp, p_top, M, p0, p_cu, kf.data_ptr(), vf.data_ptr(), self.rows_bound, st)
+        rc = self.f_gat(self.dgat_ref, kp, vp, p_top, M, given_ptr if given_ptr is not None else p0, p_cu, kf.data_ptr(), vf.data_ptr(),
+                        self.rows_bound, st)
         if rc:
             N.check(rc, "pkv_gather_flat")
         _, head_lens, cu, cuh, _ = buf.split(self.sizes)          # views for the metadata attributes: after both calls are issued

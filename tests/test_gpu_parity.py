@@ -621,6 +621,19 @@ def test_prepared_calls_follow_layout_and_knob_changes(P):
     f3 = P.AdaKVCluster(**dict(akw, floor=0.5))
     w3 = f3.update_kv(ka, qa, va)
     assert torch.equal(r3[0], w3[0]) and torch.equal(r3[1], w3[1]) and ac.head_lens.tolist() == f3.head_lens.tolist()
+    # HeadKV: the prepared call (second update_kv of a cluster) gives the first call's bytes and follows a changed capacity table
+    hc = [[40, 300, 17, 120, 64, 500, 8, 77]]
+    hk = P.HeadKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, layer_idx=0, num_hidden_layers=32,
+                         head_capacity=hc)
+    h1 = hk.update_kv(ka, qa, va)
+    h2 = hk.update_kv(ka, qa, va)
+    assert hk.__dict__.get("_fast") is not None and torch.equal(h1[0], h2[0]) and torch.equal(h1[1], h2[1])
+    assert hk.head_lens.tolist() == [c + w for c in hc[0]] and int(hk.klen_sum) == sum(hc[0]) + 8 * w == h2[0].shape[0]
+    hk.head_adaptive_capacity = [[c + 5 for c in hc[0]]]
+    h3 = hk.update_kv(ka, qa, va)
+    f3h = P.HeadKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, layer_idx=0, num_hidden_layers=32,
+                          head_capacity=[[c + 5 for c in hc[0]]]).update_kv(ka, qa, va)
+    assert torch.equal(h3[0], f3h[0]) and torch.equal(h3[1], f3h[1])
     r4 = ac.update_kv(ka[:, :, :2000].contiguous(), qa[:, :, :2000].contiguous(), va[:, :, :2000].contiguous())
     w4 = P.AdaKVCluster(**dict(akw, floor=0.5)).update_kv(ka[:, :, :2000].contiguous(), qa[:, :, :2000].contiguous(), va[:, :, :2000].contiguous())
     assert torch.equal(r4[0], w4[0]) and torch.equal(r4[1], w4[1])
