@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <string>
 #include <vector>
 #include "pkv.h"
 
@@ -22,7 +23,8 @@ static uint16_t f32_to_bf16(float f) {
 }
 static float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool with_rccl = !(argc > 1 && !strcmp(argv[1], "--no-rccl"));   // bisecting aid: skip the communicator
   const int B = 1, H = 4, S = 4096, D = 128, w = 8, cap = 64, k = cap - w, L = S - w;
   const size_t n = (size_t)B * H * S * D;
   std::vector<uint16_t> hq(n), hk(n), hv(n);
@@ -88,7 +90,7 @@ int main() {
   }
   // the one exchange step of the head-sharded path over a real RCCL communicator (this box has one GPU: nranks = 1);
   // a tensor-parallel host calls exactly this after its local pkv_compress (include/pkv.h: pkv_allgather_indices)
-  {
+  if (with_rccl) {
     ncclUniqueId uid;
     ncclComm_t comm;
     if (ncclGetUniqueId(&uid) != ncclSuccess || ncclCommInitRank(&comm, 1, uid, 0) != ncclSuccess) { printf("RCCL init failed\n"); bad = 1; }
@@ -101,7 +103,31 @@ int main() {
       std::vector<int32_t> hall((size_t)B * H * k);
       HIP_OK(hipMemcpy(hall.data(), all, hall.size() * 4, hipMemcpyDeviceToHost));
       if (memcmp(hall.data(), hidx.data(), hall.size() * 4)) { printf("pkv_allgather_indices: gathered indices differ\n"); bad = 1; }
-      ncclCommDestroy(comm);
+      HIP_OK(hipFree(all));
+      // libpkv resolved its RCCL entry points during that call: it must have taken THIS process's copy and loaded no second one
+      // (PKV_RCCL_LIB pointing at another build must be ignored here; two RCCLs in one process corrupt the heap at exit)
+      {
+        std::vector<std::string> copies;
+        if (FILE* maps = fopen("/proc/self/maps", "r")) {
+          char line[1024];
+          while (fgets(line, sizeof line, maps)) {
+            const char* path = strchr(line, '/');
+            if (!path || !strstr(path, "librccl")) continue;
+            std::string s(path);
+            while (!s.empty() && (s.back() == '\n' || s.back() == ' ')) s.pop_back();
+            bool known = false;
+            for (const std::string& c : copies) known |= c == s;
+            if (!known) copies.push_back(s);
+          }
+          fclose(maps);
+        }
+        if (copies.size() != 1) {
+          printf("%zu RCCL libraries mapped in this process (expected exactly one):\n", copies.size());
+          for (const std::string& c : copies) printf("  %s\n", c.c_str());
+          bad = 1;
+        }
+      }
+      if (ncclCommDestroy(comm) != ncclSuccess) { printf("ncclCommDestroy failed\n"); bad = 1; }
     }
   }
   // error convention: a bad descriptor is reported, nothing aborts
@@ -109,6 +135,10 @@ int main() {
   if (pkv_compress(&e, q, kk, v, ko, vo, idx, ws, wsb, stream) != PKV_ERR_SHAPE) { printf("D=100 not rejected\n"); bad = 1; }
   e = d; e.struct_size = 0;      // a host that never heard of struct_size (or an uninitialised descriptor)
   if (pkv_compress(&e, q, kk, v, ko, vo, idx, ws, wsb, stream) != PKV_ERR_ABI) { printf("struct_size 0 not rejected\n"); bad = 1; }
+  // orderly teardown: nothing of this host is left for the runtimes' exit handlers to find
+  for (void* p : {q, kk, v, ko, vo, ws, sc, (void*)idx}) HIP_OK(hipFree(p));
+  HIP_OK(hipStreamDestroy(stream));
   printf(bad ? "host_cabi: FAILED\n" : "host_cabi: ok (pkv_version %d, %d heads x top-%d of %d, workspace %zu bytes)\n", pkv_version(), B * H, k, L, wsb);
+  fflush(stdout);
   return bad;
 }

@@ -263,7 +263,8 @@ PKV_API int pkv_update_flatten_view(int32_t dtype, int32_t H, int32_t head_dim, 
  * idx_all int32 [B][nranks*H_local][k] (heads in rank order).  ONE ncclAllGather on `stream`; for B > 1 plus one small
  * regroup kernel (rank-major -> head-major), which needs ws >= nranks*B*H_local*k*4 bytes (ws may be NULL for B == 1).
  * nccl_comm is the caller's ncclComm_t (libpkv creates none and does not link RCCL: the entry points are taken from the
- * RCCL already loaded in the process - PyTorch's, or the one named by PKV_RCCL_LIB, else librccl.so.1).
+ * RCCL already loaded in the process - PyTorch's or the host's own; only a process without one gets the library named
+ * by PKV_RCCL_LIB, else librccl.so.1: a process must hold ONE RCCL, two copies corrupt the heap at exit).
  * PyTorch does not expose its communicator, so the Python host issues the same collective through torch.distributed
  * (pyramidkv_amd/dist.py); a C/C++ host calls this. */
 PKV_API int pkv_allgather_indices(void* nccl_comm, const int32_t* idx_local, int32_t* idx_all, int32_t B, int32_t H_local,

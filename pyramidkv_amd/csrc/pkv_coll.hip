@@ -4,7 +4,8 @@
 //
 // libpkv does not link RCCL: a process must talk to ONE RCCL (PyTorch ships its own librccl.so), so the three entry
 // points needed are resolved at first use from whichever RCCL the process already has (global scope, then the
-// already-loaded library by soname, then a plain dlopen).  No communicator is created here: the caller owns it.
+// already-loaded library by soname; only when there is none: PKV_RCCL_LIB, then a plain dlopen of the system library).  No
+// communicator is created here: the caller owns it.
 #include "../../include/pkv.h"
 #include "pkv_kernels.hpp"
 
@@ -34,12 +35,10 @@ const Rccl& rccl() {
   std::lock_guard<std::mutex> lk(g_rccl_mu);
   if (g_rccl.tried) return g_rccl;
   g_rccl.tried = true;
-  void* handles[6] = {RTLD_DEFAULT, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* handles[4] = {RTLD_DEFAULT, nullptr, nullptr, nullptr};
   const char* names[] = {"librccl.so", "librccl.so.1"};
   int nh = 1;
   for (const char* n : names) handles[nh++] = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // the copy already in the process
-  const char* env = getenv("PKV_RCCL_LIB");                                                // explicit path, if any
-  if (env && *env) handles[nh++] = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
   for (int i = 0; i < nh && !g_rccl.all_gather; ++i) {
     if (i > 0 && !handles[i]) continue;
     void* ag = i == 0 ? dlsym(RTLD_DEFAULT, "ncclAllGather") : lookup(handles[i], "ncclAllGather");
@@ -49,8 +48,10 @@ const Rccl& rccl() {
     g_rccl.comm_count = reinterpret_cast<nccl_count_fn>(i == 0 ? dlsym(RTLD_DEFAULT, "ncclCommCount") : lookup(h, "ncclCommCount"));
     g_rccl.err_string = reinterpret_cast<nccl_errstr_fn>(i == 0 ? dlsym(RTLD_DEFAULT, "ncclGetErrorString") : lookup(h, "ncclGetErrorString"));
   }
-  if (!g_rccl.all_gather) {                                                                // nothing loaded yet: load the system RCCL
-    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+  if (!g_rccl.all_gather) {                       // nothing loaded yet: PKV_RCCL_LIB (explicit path) first, then the system RCCL.
+    const char* env = getenv("PKV_RCCL_LIB");     // Never consulted when the process already holds an RCCL: a second copy
+    for (const char* n : {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {   // next to it corrupts the heap at exit
+      if (!n || !*n) continue;
       void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (!h) continue;
       g_rccl.all_gather = reinterpret_cast<nccl_allgather_fn>(dlsym(h, "ncclAllGather"));

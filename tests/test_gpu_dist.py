@@ -171,8 +171,7 @@ def test_cabi_allgather_indices_over_rccl_nranks1():
     path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
     if not os.path.exists(path):
         path = "/opt/rocm/lib/librccl.so.1"
-    os.environ["PKV_RCCL_LIB"] = path
-    rccl = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    rccl = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)             # libpkv finds this copy by itself (no PKV_RCCL_LIB)
 
     class UniqueId(ctypes.Structure):
         _fields_ = [("internal", ctypes.c_char * 128)]

@@ -1029,17 +1029,28 @@ def test_update_kv_is_graph_capturable(P):
     assert torch.equal(kc, kc2_ref) and torch.equal(vc, vc2_ref)
 
 
-def test_c_host_without_python_bindings(P):
+@pytest.mark.parametrize("rccl_env", ["unset", "another_build"])
+def test_c_host_without_python_bindings(P, rccl_env):
     """examples/host_cabi.cpp: a C++ host using only include/pkv.h and the HIP runtime (no torch, no ctypes) runs
-    SnapKV update_kv through the C ABI and verifies selection order, dominance, gather and the error convention."""
+    SnapKV update_kv through the C ABI and verifies selection order, dominance, gather, the one exchange step on its own
+    RCCL communicator and the error convention.  Second case: PKV_RCCL_LIB names ANOTHER RCCL build (PyTorch's) - a process
+    that already holds an RCCL must not get a second one from libpkv (the example counts the copies mapped; two copies
+    made it die in its exit handlers: "corrupted size vs. prev_size in fastbins", LABNOTES round 5)."""
     import subprocess
     exe = os.path.join(ROOT, "examples", "host_cabi")
     if not os.path.exists(exe):
         import __graft_entry__ as g
         g.build()
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "host_cabi: ok" in r.stdout
+    env = {k: v for k, v in os.environ.items() if k != "PKV_RCCL_LIB"}
+    if rccl_env == "another_build":
+        other = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if not os.path.exists(other):
+            pytest.skip("no second RCCL build on this box")
+        env["PKV_RCCL_LIB"] = other
+    for _ in range(3):                       # the teardown failure was intermittent: three clean exits, not one
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "host_cabi: ok" in r.stdout
 
 
 # ----------------------------------------------------------------------------------------- golden fixtures
