@@ -123,3 +123,59 @@ def test_oracle_equals_the_live_reference_on_random_configurations(policy):
                 assert np.array_equal(getattr(meta, name).numpy(), getattr(cl, name).numpy()), (name, c)
             assert meta.max_seqlen_k == int(cl.max_seqlen_k) and meta.klen_sum == int(cl.klen_sum), c
     assert ran >= 30 and compressed >= 20, (ran, compressed)
+
+
+def _recover_indices(K, Kc_past):
+    """K [B,H,L,D] source rows, Kc_past [B,H,k,D] gathered rows -> int64 [B,H,k]; None when a head holds duplicate rows."""
+    B, H, L, _ = K.shape
+    k = Kc_past.shape[2]
+    out = np.zeros((B, H, k), dtype=np.int64)
+    Kb, Cb = bits(K), bits(Kc_past)
+    for b in range(B):
+        for h in range(H):
+            table = {Kb[b, h, s].tobytes(): s for s in range(L)}
+            if len(table) != L:
+                return None
+            for j in range(k):
+                out[b, h, j] = table[Cb[b, h, j].tobytes()]
+    return torch.from_numpy(out)
+
+
+@pytest.mark.parametrize("policy", ("snapkv", "pyramidkv", "h2o"))
+def test_canonical_tie_rule_selects_what_the_live_reference_selected(policy):
+    """What the HIP path implements is the oracle's CANONICAL tie rule (descending score, ascending index among equals); the
+    reference's CPU topk orders equal scores its own way.  On random configurations the two select the same score-value
+    sequence per head (O.equivalent_selection), and the same indices wherever the selected scores are distinct."""
+    rng = np.random.default_rng(777 + POLICIES.index(policy))
+    checked = identical_rows = 0
+    for _ in range(30):
+        c = random_case(rng, policy)
+        c.pop("merge", None)
+        q, k, v = make_qkv(c["B"], c["H"], c["S"], 128, c["dtype"], c["kind"], c["seed"])
+        kr, _, _ = run_reference(c, q, k, v)
+        if kr is k:
+            continue
+        w = c["w"]
+        ref_idx = _recover_indices(k[:, :, :-w], kr[:, :, :kr.shape[2] - w])
+        if ref_idx is None or ref_idx.shape[2] == 0:
+            continue
+        if policy == "snapkv":
+            out = O.snapkv_update_kv(k, q, v, w, c["cap"], c["ks"], c["pool"], topk_mode="canonical", return_indices=True)
+        elif policy == "pyramidkv":
+            out = O.pyramidkv_update_kv(k, q, v, w, c["cap"], c["ks"], c["pool"], c["layers"], c["layer"], topk_mode="canonical",
+                                        return_indices=True)
+        else:
+            out = O.h2o_update_kv(k, q, v, w, c["cap"], topk_mode="canonical", return_indices=True)
+        idx = out[2]
+        s = O.h2o_scores(q, k, w) if policy == "h2o" else O.pool_scores(O.window_scores(q, k, w, "sum"), c["pool"], c["ks"])
+        assert idx.shape == ref_idx.shape, c
+        assert O.equivalent_selection(idx, ref_idx, s), c
+        checked += 1
+        for b in range(idx.shape[0]):
+            for h in range(idx.shape[1]):
+                row = s[b, h].float()
+                sel = row[idx[b, h]]
+                if sel.unique().numel() == sel.numel() and int((row == sel[-1]).sum()) == 1:
+                    assert torch.equal(idx[b, h], ref_idx[b, h]), c
+                    identical_rows += 1
+    assert checked >= 10 and identical_rows >= 3, (checked, identical_rows)
