@@ -37,7 +37,11 @@ for name in ("bench.json", "sweep.json", "bw_probe.json", "parity_report.json", 
     elif name == "parity_report.json" and os.path.exists(os.path.join(ROOT, "gpurun_out", name)):
         shutil.copy(os.path.join(ROOT, "gpurun_out", name), os.path.join(P, name))     # the suite ran in its own gpurun call
 lines = ["# Profiles, round r05\n", "All numbers measured on one MI355X (gfx950) through `gpurun` by `tools/r05_full_session.sh`; raw files sit next to "
-         "this summary.  Kernel sources: sha16 `%s`.\n" % src_sha()]
+         "this summary.  Kernel sources: sha16 `%s`.  The rocprofv3 --stats files, the issue-port counters, the parity sweep "
+         "and the H2O / merge records were written by the full session at sha16 `d5358b59e01886d7`; the one source edit since "
+         "is host code (`pkv_coll.hip`: which RCCL library gets opened) - no kernel changed - and the closing session "
+         "(`tools/archive/r05_final_check3.sh`) re-ran the HBM traffic passes, the driver's bench command, the suite and smoke "
+         "on the final library (`pmc_traffic.json`, `bench.json`, `pytest.txt`, `smoke.log`).\n" % src_sha()]
 
 
 def stats_table(pattern, title, top=8):
