@@ -24,6 +24,8 @@
 #include "pkv_mfma.hpp"
 
 #include <algorithm>
+#include <stdlib.h>
+#include <type_traits>
 
 namespace pkv {
 
@@ -262,6 +264,248 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS == 8 ? 3
   }
 }
 
+// ---- 4b. pivot, pipelined (round 6): the same result as merge_pivot_kernel, organised like the K scan (logits2_kernel) ----
+// Head size 128 and at most MP2_TN kept rows (budget 128 + window 8: what the runners use) - everything else keeps the kernel
+// above.  What was slow there (151 us for 268 MB at S = 32768 = 0.22 of HBM): every workgroup paid three dependent round
+// trips (ndrop -> drop list -> rows) before its first instruction of arithmetic, all workgroups of a round did so in lockstep,
+// the row loads fetched 64-byte pieces of 16 different rows per instruction, and ~1800 vector instructions per wave went
+// into the normalisation and the arg-max keys.  Here a workgroup owns `nst` consecutive stages of 128 dropped rows of one
+// head; per stage and wave 8 nontemporal row-major 1-KB loads (4 whole rows per instruction) land in registers while the
+// previous stage is processed, the drop-list entries of the stage after that are fetched at the same time (one pipeline
+// instead of three round trips per 256 rows), the rows go through a wave-private XOR-swizzled LDS transpose into the SAME
+// MFMA fragments the kernel above builds, and from there on the arithmetic is the same instruction for instruction - the
+// pivots are bit-identical by construction - with two cheaper forms:
+//   * bf16: dtype(x / n) == dtype(x * fp32(1/n)) for every bf16 x and every NORMAL bf16 n: a quotient of two 8-bit
+//     significands is never a bf16 rounding midpoint (that needs a 9-bit odd factor) and is at least 2^-17 (relative) away
+//     from one, the multiply's error is below 2^-23.  Rows whose norm is zero / subnormal / not finite (wave-uniform test)
+//     take div_const as above.  fp16 (11-bit significands: the gap shrinks to the error) always divides.
+//   * arg-max keys: raw 16-bit pattern << 16 | (0xffff - column) compared as SIGNED integers orders all non-negative
+//     similarities correctly and puts every negative one below them; a row whose maximum is not above +0 (or a wave that can
+//     see a NaN) is redone with the exact order-preserving keys of the kernel above (wave-uniform, ~never for real keys: the
+//     observation-window rows are among the kept rows).
+constexpr int MP2_TN = 144;               // kept rows of the one LDS tile
+constexpr int MP2_TROW = 128 + 8;         // its row stride in elements (as MergeShape<4>::TROW)
+constexpr int MP2_HT = 128;               // dropped rows per stage (4 waves x 32)
+
+__device__ __forceinline__ int dpp_max16_i32(int x) {          // maximum over the 16 lanes of a DPP row, in every lane
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));     // row_half_mirror
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));     // row_mirror
+  return x;
+}
+__device__ __forceinline__ uint32_t dpp_max16_u32(uint32_t x) {
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));
+  return x;
+}
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void merge_pivot2_kernel(MergeParams p, int nst) {
+  constexpr int KS = 4, D = 128, CPR = D / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char mp2_smem[];
+  u32x4* kst_all = reinterpret_cast<u32x4*>(mp2_smem);                          // [4 waves][32 rows][16 chunks], 32 KB
+  uint16_t* tile = reinterpret_cast<uint16_t*>(mp2_smem + 32768);               // [MP2_TN][MP2_TROW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  u32x4* kst = kst_all + wave * 512;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
+  const int n = *p.ndrop;
+  const int row_wg = blockIdx.x * nst * MP2_HT;
+  if (row_wg >= n) return;
+  const int nh = min(nst, (n - row_wg + MP2_HT - 1) / MP2_HT);
+  const int nt = p.k + p.w;                                                     // <= MP2_TN (launch_merge_t)
+  const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h;
+  const uint16_t* tn = reinterpret_cast<const uint16_t*>(p.tn) + (int64_t)bh * p.ntp * D;
+  int32_t* pivot = p.pivot + (int64_t)bh * p.S;
+
+  // the pipeline: positions of stage s+2 | rows of stage s+1 | arithmetic of stage s
+  int idn[8];
+  auto issue_idx = [&](int s) {
+    const int r0 = row_wg + s * MP2_HT + wave * 32 + lg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int r = r0 + 4 * j; idn[j] = p.drop[r < n ? r : n - 1]; }   // clamp: rows past n are never written
+  };
+  u32x4 pre[8];
+  auto issue_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int rl = 4 * j + lg;
+      const u32x4* ptr = reinterpret_cast<const u32x4*>(kbase + (int64_t)idn[j] * p.ks_s) + (li ^ (rl & 15));
+      pre[j] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
+    }
+  };
+  issue_idx(0);
+  issue_rows();
+  if (nh > 1) issue_idx(1);
+  for (int c = tid; c < MP2_TN * CPR; c += 256) {                               // the head's unit-norm kept keys, once; rows past nt are zero
+    const int rr = c / CPR, ch = c - rr * CPR;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (rr < nt) val = reinterpret_cast<const uint4*>(tn + (int64_t)rr * D)[ch];
+    *reinterpret_cast<uint4*>(tile + rr * MP2_TROW + ch * 8) = val;
+  }
+  const bool kept_bad = p.kept_bad[bh] != 0;
+  __syncthreads();
+  const int nfull = nt >> 4, ntail = nt & 15;
+
+  for (int s = 0; s < nh; ++s) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kst[j * 64 + lane] = pre[j];
+    if (s + 1 < nh) {
+      issue_rows();
+      if (s + 2 < nh) issue_idx(s + 2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    u32x4 af[2][KS];                                                            // row li of group t = dropped row (stage) + wave*32 + t*16 + li
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) af[t][kk] = kst[(t * 16 + li) * 16 + ((kk * 4 + lg) ^ li)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                                            // every lane has its fragments: the staging area is free again
+
+    // unit-norm rows in registers: the summation order of merge_pivot_kernel (8 elements x 4 k-steps per lane, then the 4 lanes of a row)
+    bool bad_row = false;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float xs[KS * 8];
+      float n2 = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        U4 u;
+        u.v = make_uint4(af[t][kk].x, af[t][kk].y, af[t][kk].z, af[t][kk].w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xs[kk * 8 + e] = Elem<T>::to_f32(u.h[e]); n2 += xs[kk * 8 + e] * xs[kk * 8 + e]; }
+      }
+      n2 += __shfl_xor(n2, 16, 64);
+      n2 += __shfl_xor(n2, 32, 64);
+      const float nr = Elem<T>::to_f32(Elem<T>::from_f32(sqrtf(n2)));
+      const bool bad = !(n2 < INFINITY) || !(nr > 0.f);
+      bad_row |= bad;
+      const float rn = 1.0f / nr;
+      bool divide = true;
+      if constexpr (std::is_same<T, BF16>::value)                              // bf16 (see the head of this kernel)
+        divide = __ballot(bad || !(nr >= 1.17549435e-38f)) != 0ull;
+      if (divide) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          u32x4 a;
+          a.x = round_pack2<T>(div_const(xs[kk * 8 + 0], nr, rn), div_const(xs[kk * 8 + 1], nr, rn));
+          a.y = round_pack2<T>(div_const(xs[kk * 8 + 2], nr, rn), div_const(xs[kk * 8 + 3], nr, rn));
+          a.z = round_pack2<T>(div_const(xs[kk * 8 + 4], nr, rn), div_const(xs[kk * 8 + 5], nr, rn));
+          a.w = round_pack2<T>(div_const(xs[kk * 8 + 6], nr, rn), div_const(xs[kk * 8 + 7], nr, rn));
+          af[t][kk] = a;
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          u32x4 a;
+          a.x = round_pack2<T>(xs[kk * 8 + 0] * rn, xs[kk * 8 + 1] * rn);
+          a.y = round_pack2<T>(xs[kk * 8 + 2] * rn, xs[kk * 8 + 3] * rn);
+          a.z = round_pack2<T>(xs[kk * 8 + 4] * rn, xs[kk * 8 + 5] * rn);
+          a.w = round_pack2<T>(xs[kk * 8 + 6] * rn, xs[kk * 8 + 7] * rn);
+          af[t][kk] = a;
+        }
+      }
+    }
+    bool exact = kept_bad || __ballot(bad_row) != 0ull;                         // wave-uniform
+    uint32_t res[2][4];                                                         // low 16 bits: 0xffff - kept-row number of the first maximum
+    if (!exact) {
+      int best[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) best[t][r] = (int)0x80000000;
+      auto tile16 = [&](int n16, bool tail) {
+        u32x4 bf[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) bf[kk] = *reinterpret_cast<const u32x4*>(tile + (n16 * 16 + li) * MP2_TROW + kk * 32 + lg * 8);
+        const uint32_t colkey = 0xffffu - (uint32_t)(n16 * 16 + li);
+        const bool valid = !tail || li < ntail;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk) acc = Mfma<T>::run(af[t][kk], bf[kk], acc);
+          const uint32_t p01 = round_pack2<T>(acc[0], acc[1]), p23 = round_pack2<T>(acc[2], acc[3]);   // similarities in the model dtype (:150)
+          int k0 = (int)((p01 << 16) | colkey), k1 = (int)((p01 & 0xffff0000u) | colkey);
+          int k2 = (int)((p23 << 16) | colkey), k3 = (int)((p23 & 0xffff0000u) | colkey);
+          if (tail) {
+            k0 = valid ? k0 : (int)0x80000000; k1 = valid ? k1 : (int)0x80000000;
+            k2 = valid ? k2 : (int)0x80000000; k3 = valid ? k3 : (int)0x80000000;
+          }
+          best[t][0] = max(best[t][0], k0); best[t][1] = max(best[t][1], k1);
+          best[t][2] = max(best[t][2], k2); best[t][3] = max(best[t][3], k3);
+        }
+      };
+      for (int n16 = 0; n16 < nfull; ++n16) tile16(n16, false);
+      if (ntail) tile16(nfull, true);
+      bool redo = false;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kx = dpp_max16_i32(best[t][r]);
+          redo |= kx < 0x00010000;                                              // the row's maximum is not above +0: signed order is not enough
+          res[t][r] = (uint32_t)kx;
+        }
+      exact = __ballot(redo) != 0ull;
+    }
+    if (exact) {                                                                // merge_pivot_kernel's keys: total order incl. negative values, NaN first
+      uint32_t bestk[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bestk[t][r] = 0u;
+      for (int n16 = 0; n16 * 16 < nt; ++n16) {
+        u32x4 bf[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) bf[kk] = *reinterpret_cast<const u32x4*>(tile + (n16 * 16 + li) * MP2_TROW + kk * 32 + lg * 8);
+        const int col = n16 * 16 + li;
+        const uint32_t colkey = col < nt ? 0xffffu - (uint32_t)col : 0xffffffffu;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk) acc = Mfma<T>::run(af[t][kk], bf[kk], acc);
+          uint32_t pk[2] = {round_pack2<T>(acc[0], acc[1]), round_pack2<T>(acc[2], acc[3])};
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const uint32_t neg = (pk[h2] >> 15) & 0x00010001u;
+            uint32_t m = pk[h2] ^ ((neg * 0xffffu) | 0x80008000u);
+            if (Elem<T>::is_nan((uint16_t)(pk[h2] & 0xffffu))) m |= 0x0000ffffu;
+            if (Elem<T>::is_nan((uint16_t)(pk[h2] >> 16))) m |= 0xffff0000u;
+            const uint32_t k0 = (m << 16) | colkey, k1 = (m & 0xffff0000u) | colkey;
+            if (colkey != 0xffffffffu) {
+              bestk[t][2 * h2] = max(bestk[t][2 * h2], k0);
+              bestk[t][2 * h2 + 1] = max(bestk[t][2 * h2 + 1], k1);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[t][r] = dpp_max16_u32(bestk[t][r]);
+    }
+    if (li == 0) {
+      const int rbase = row_wg + s * MP2_HT + wave * 32 + lg * 4;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rbase + t * 16 + r;
+          if (row < n) pivot[row] = (int32_t)(0xffffu - (res[t][r] & 0xffffu));
+        }
+    }
+  }
+}
+
 // ---- 5. bucket: per (b,h) the dropped rows grouped by the kept row they chose (counting sort over the pivots) ----
 // One workgroup of 1024 threads per head: LDS histogram over a range of MB_RANGE kept rows, exclusive scan (written out as
 // bstart[bh][j]), placement through LDS cursors.  blist holds the dropped POSITIONS; within a group the order is whatever
@@ -433,6 +677,20 @@ __global__ __launch_bounds__(KS * 32) void merge_scatter_kernel(MergeParams p) {
   *reinterpret_cast<uint32_t*>(out) = round_pack2<T>(Elem<T>::to_f32((uint16_t)(sq & 0xffffu)) / cnt_q, Elem<T>::to_f32((uint16_t)(sq >> 16)) / cnt_q);
 }
 
+// knobs of the pipelined pivot kernel (identical results; defaults are the measured best, env vars exist for A/B runs)
+static int merge_env(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static int merge_pivot2_on() { static int t = merge_env("PKV_MERGE_PIVOT2", 1); return t; }
+static int merge_pivot2_nst() { static int t = merge_env("PKV_MERGE_NST", 0); return t; }       // 0 = by size
+static int merge_pivot2_nt() { static int t = merge_env("PKV_MERGE_NT", 1); return t; }         // nontemporal row loads
+static int merge_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
 template <typename T, int KS>
 hipError_t launch_merge_t(const MergeParams& p, hipStream_t st) {
   using Sh = MergeShape<KS>;
@@ -440,7 +698,29 @@ hipError_t launch_merge_t(const MergeParams& p, hipStream_t st) {
   const dim3 gt((nt + 3) / 4, p.B * p.H), gp((p.S + MP_ROWS * Sh::ITER - 1) / (MP_ROWS * Sh::ITER), p.B * p.H), gs(nt, p.B * p.H);
   const size_t bitmap_bytes = (size_t)((p.S + 31) / 32) * 4;
   hipLaunchKernelGGL((merge_targets_kernel<T, KS>), gt, dim3(256), 0, st, p);
-  hipLaunchKernelGGL((merge_pivot_kernel<T, KS>), gp, dim3(256), 0, st, p);
+  bool pipelined = false;
+  if constexpr (KS == 4) {
+    if (nt <= MP2_TN && merge_pivot2_on()) {
+      // stages per workgroup: two rounds of workgroups over the chip's 2-per-CU residency (LDS: 70 KB each), at most 16
+      const int64_t stages = (int64_t)p.B * p.H * ((p.S + MP2_HT - 1) / MP2_HT);
+      int nst = merge_pivot2_nst();
+      if (nst <= 0) nst = (int)std::max<int64_t>(1, std::min<int64_t>(16, stages / (4 * merge_cus())));
+      const dim3 g2((p.S + nst * MP2_HT - 1) / (nst * MP2_HT), p.B * p.H);
+      const size_t lds = 32768 + (size_t)MP2_TN * MP2_TROW * 2;
+      hipError_t e;
+      if (merge_pivot2_nt()) {
+        e = dyn_lds(reinterpret_cast<const void*>(merge_pivot2_kernel<T, true>), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((merge_pivot2_kernel<T, true>), g2, dim3(256), lds, st, p, nst);
+      } else {
+        e = dyn_lds(reinterpret_cast<const void*>(merge_pivot2_kernel<T, false>), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((merge_pivot2_kernel<T, false>), g2, dim3(256), lds, st, p, nst);
+      }
+      pipelined = true;
+    }
+  }
+  if (!pipelined) hipLaunchKernelGGL((merge_pivot_kernel<T, KS>), gp, dim3(256), 0, st, p);
   hipLaunchKernelGGL(merge_bucket_kernel, dim3(p.B * p.H), dim3(1024), 0, st, p);
   hipLaunchKernelGGL((merge_scatter_kernel<T, KS>), gs, dim3(KS * 32), bitmap_bytes, st, p);
   return hipGetLastError();
