@@ -29,6 +29,8 @@
 
 namespace pkv {
 
+static int merge_env(const char* name, int dflt);
+
 // ---- 1. union bitmap: mask[p] = 1 iff some (b,h) selected p ----
 __global__ __launch_bounds__(256) void merge_mark_kernel(MergeParams p) {
   const int64_t total = (int64_t)p.B * p.H * p.k;
@@ -92,6 +94,52 @@ __global__ __launch_bounds__(1024) void merge_droplist_kernel(MergeParams p) {
         if (((wd[q] >> (8 * bq)) & 0xffu) == 0u) p.drop[at++] = s0 + c + q * 4 + bq;
   }
   if (tid == 0) *p.ndrop = (int32_t)all;
+}
+
+// ---- 2b. the same list from several workgroups (round 6; the one-workgroup form above took 17 us at S = 32768) ----
+// Workgroup g owns the positions [4096 g, 4096 (g + 1)): it first counts the dropped positions BELOW its slice (the mask
+// is S bytes, L2-resident: at most S / 16 sixteen-byte loads spread over 256 threads), then compacts its own slice in order.
+// A mask byte is 0 or 1, so a dword holds 4 - popcount dropped positions.  The last workgroup writes the total.
+constexpr int MD_SLICE = 4096;
+__global__ __launch_bounds__(256) void merge_droplist2_kernel(MergeParams p) {
+  __shared__ uint32_t wsum[4], wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s_begin = blockIdx.x * MD_SLICE;
+  uint32_t below = 0;
+  for (int s = tid * 16; s < s_begin; s += 256 * 16) {                       // s + 16 <= s_begin <= S: whole 16-byte words
+    const uint4 v = *reinterpret_cast<const uint4*>(p.mask + s);
+    below += 16u - (uint32_t)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
+  }
+  below = wave_sum_u32(below);
+  if (lane == 0) wsum[wave] = below;
+  const int s0 = s_begin + tid * 16;
+  uint32_t wd[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};     // positions >= S read as selected
+  if (s0 + 16 <= p.S) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p.mask + s0);
+    wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w;
+  } else if (s0 < p.S) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) { const int sp = s0 + q * 4 + bq; x |= (uint32_t)(sp < p.S ? p.mask[sp] : 1) << (8 * bq); }
+      wd[q] = x;
+    }
+  }
+  const uint32_t cnt = 16u - (uint32_t)(__popc(wd[0] & 0x01010101u) + __popc(wd[1] & 0x01010101u) + __popc(wd[2] & 0x01010101u) + __popc(wd[3] & 0x01010101u));
+  const uint32_t incl = wave_incl_scan_u32(cnt);
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t lower = wsum[0] + wsum[1] + wsum[2] + wsum[3], all = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < 4; ++w2) { const uint32_t c = wtot[w2]; all += c; lower += w2 < wave ? c : 0u; }
+  uint32_t at = lower + incl - cnt;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq)
+      if (((wd[q] >> (8 * bq)) & 1u) == 0u) p.drop[at++] = s0 + q * 4 + bq;
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) *p.ndrop = (int32_t)(wsum[0] + wsum[1] + wsum[2] + wsum[3] + all);
 }
 
 // kept row j of the KEY order [window, selected] (:146): source position in K
@@ -283,35 +331,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS == 8 ? 3
 //     similarities correctly and puts every negative one below them; a row whose maximum is not above +0 (or a wave that can
 //     see a NaN) is redone with the exact order-preserving keys of the kernel above (wave-uniform, ~never for real keys: the
 //     observation-window rows are among the kept rows).
-constexpr int MP2_TN = 144;               // kept rows of the one LDS tile
-constexpr int MP2_TROW = 128 + 8;         // its row stride in elements (as MergeShape<4>::TROW)
+constexpr int MP2_TN = 144;               // kept rows of the one LDS tile: [MP2_TN][16 chunks of 16 B], chunk c of row r at slot c ^ (r & 15)
 constexpr int MP2_HT = 128;               // dropped rows per stage (4 waves x 32)
+constexpr int MP2_STAGE_BYTES = 4 * 4096; // wave-private transpose areas: 16 rows x 256 B each (a stage goes through in two halves)
+constexpr int MP2_LDS_BYTES = MP2_STAGE_BYTES + MP2_TN * 256;   // 53 248 B: three workgroups per CU
 
 __device__ __forceinline__ int dpp_max16_i32(int x) {          // maximum over the 16 lanes of a DPP row, in every lane
-  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
-  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
-  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));     // row_half_mirror
-  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));     // row_mirror
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true));       // quad_perm [2,3,0,1]
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true));      // row_half_mirror
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true));      // row_mirror
   return x;
 }
 __device__ __forceinline__ uint32_t dpp_max16_u32(uint32_t x) {
-  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));
-  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));
-  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));
-  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, true));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, true));
   return x;
 }
 
-template <typename T, bool NT>
-__global__ __launch_bounds__(256) void merge_pivot2_kernel(MergeParams p, int nst) {
+template <typename T, bool NT, int PF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF == 1 ? 3 : 2))) void merge_pivot2_kernel(MergeParams p, int nst, uint32_t row_bytes) {
   constexpr int KS = 4, D = 128, CPR = D / 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char mp2_smem[];
-  u32x4* kst_all = reinterpret_cast<u32x4*>(mp2_smem);                          // [4 waves][32 rows][16 chunks], 32 KB
-  uint16_t* tile = reinterpret_cast<uint16_t*>(mp2_smem + 32768);               // [MP2_TN][MP2_TROW]
+  u32x4* kst_all = reinterpret_cast<u32x4*>(mp2_smem);                          // [4 waves][16 rows][16 chunks]
+  u32x4* tile = reinterpret_cast<u32x4*>(mp2_smem + MP2_STAGE_BYTES);           // [MP2_TN][16 chunks], swizzled
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  u32x4* kst = kst_all + wave * 512;
+  u32x4* kst = kst_all + wave * 256;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H, hk = h / p.G;
   const int n = *p.ndrop;
   const int row_wg = blockIdx.x * nst * MP2_HT;
@@ -322,52 +371,78 @@ __global__ __launch_bounds__(256) void merge_pivot2_kernel(MergeParams p, int ns
   const uint16_t* tn = reinterpret_cast<const uint16_t*>(p.tn) + (int64_t)bh * p.ntp * D;
   int32_t* pivot = p.pivot + (int64_t)bh * p.S;
 
-  // the pipeline: positions of stage s+2 | rows of stage s+1 | arithmetic of stage s
-  int idn[8];
-  auto issue_idx = [&](int s) {
+  // the pipeline: positions of stage s+PF+1 | rows of stages s+1 .. s+PF (PF register sets) | arithmetic of stage s
+  auto issue_idx = [&](int s, int (&id)[8]) {
     const int r0 = row_wg + s * MP2_HT + wave * 32 + lg;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const int r = r0 + 4 * j; idn[j] = p.drop[r < n ? r : n - 1]; }   // clamp: rows past n are never written
+    for (int j = 0; j < 8; ++j) { const int r = r0 + 4 * j; id[j] = p.drop[r < n ? r : n - 1]; }   // clamp: rows past n are never written
   };
-  u32x4 pre[8];
-  auto issue_rows = [&]() {
+  // row j of a lane's eight: rows 4j + lg of the wave's 32, chunk li ^ ((4j + lg) & 15) - the swizzle only depends on j & 3
+  const char* lane_base[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) lane_base[j] = reinterpret_cast<const char*>(kbase) + ((li ^ ((4 * j + lg) & 15)) << 4);
+  auto issue_rows = [&](const int (&id)[8], u32x4 (&pre)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int rl = 4 * j + lg;
-      const u32x4* ptr = reinterpret_cast<const u32x4*>(kbase + (int64_t)idn[j] * p.ks_s) + (li ^ (rl & 15));
+      const u32x4* ptr = reinterpret_cast<const u32x4*>(lane_base[j & 3] + (uint64_t)(uint32_t)id[j] * row_bytes);   // v_mad_u64_u32
       pre[j] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
     }
   };
-  issue_idx(0);
-  issue_rows();
-  if (nh > 1) issue_idx(1);
+  int idn[8];
+  u32x4 preA[8], preB[PF == 2 ? 8 : 1];
+  {
+    int id0[8], id1[8];
+    issue_idx(0, id0);                                                          // all position loads of the prologue leave together
+    if (nh > 1) issue_idx(1, id1);
+    if (PF == 2 && nh > 2) issue_idx(2, idn);
+    issue_rows(id0, preA);
+    if constexpr (PF == 2) {
+      if (nh > 1) issue_rows(id1, preB);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) idn[j] = id1[j];
+    }
+  }
   for (int c = tid; c < MP2_TN * CPR; c += 256) {                               // the head's unit-norm kept keys, once; rows past nt are zero
     const int rr = c / CPR, ch = c - rr * CPR;
     uint4 val = make_uint4(0, 0, 0, 0);
     if (rr < nt) val = reinterpret_cast<const uint4*>(tn + (int64_t)rr * D)[ch];
-    *reinterpret_cast<uint4*>(tile + rr * MP2_TROW + ch * 8) = val;
+    tile[rr * 16 + (ch ^ (rr & 15))] = __builtin_bit_cast(u32x4, val);
   }
   const bool kept_bad = p.kept_bad[bh] != 0;
   __syncthreads();
   const int nfull = nt >> 4, ntail = nt & 15;
-
-  for (int s = 0; s < nh; ++s) {
+  // B fragments: lane (li, lg) reads row 16 n + li, chunk 4 kk + lg -> slot (4 kk + lg) ^ li (16 lanes of a row group: 16 different slots)
+  const u32x4* tile_l[KS];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) kst[j * 64 + lane] = pre[j];
-    if (s + 1 < nh) {
-      issue_rows();
-      if (s + 2 < nh) issue_idx(s + 2);
-    }
+  for (int kk = 0; kk < KS; ++kk) tile_l[kk] = tile + li * 16 + ((kk * 4 + lg) ^ li);
+  // the lane of each 16-lane group that stores pivot (t, r): li = 4 t + r
+  const int st_t = (li >> 2) & 1, st_r = li & 3;
+
+  auto stage = [&](int s, u32x4 (&pre)[8]) {
+    for (int j = 0; j < 4; ++j) kst[j * 64 + lane] = pre[j];                    // rows 0..15 of the wave's 32
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     u32x4 af[2][KS];                                                            // row li of group t = dropped row (stage) + wave*32 + t*16 + li
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) af[t][kk] = kst[(t * 16 + li) * 16 + ((kk * 4 + lg) ^ li)];
+    for (int kk = 0; kk < KS; ++kk) af[0][kk] = kst[li * 16 + ((kk * 4 + lg) ^ li)];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                                            // every lane has its fragments: the staging area is free again
+    __builtin_amdgcn_wave_barrier();                                            // every lane has its fragments: the area takes the second half
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kst[j * 64 + lane] = pre[4 + j];                // rows 16..31
+    if (s + PF < nh) {
+      issue_rows(idn, pre);
+      if (s + PF + 1 < nh) issue_idx(s + PF + 1, idn);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) af[1][kk] = kst[li * 16 + ((kk * 4 + lg) ^ li)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                                            // the staging area is free for the next stage
 
     // unit-norm rows in registers: the summation order of merge_pivot_kernel (8 elements x 4 k-steps per lane, then the 4 lanes of a row)
     bool bad_row = false;
@@ -421,18 +496,26 @@ __global__ __launch_bounds__(256) void merge_pivot2_kernel(MergeParams p, int ns
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) best[t][r] = (int)0x80000000;
-      auto tile16 = [&](int n16, bool tail) {
-        u32x4 bf[KS];
+      // The B fragments of tile n+1 are read while the MFMAs of tile n run, and the keys of tile n-1 are formed behind the
+      // MFMAs of tile n (they do not depend on them): LDS latency, matrix pipe and vector pipe overlap inside one wave.
+      auto load_b = [&](u32x4 (&bf)[KS], int n16) {
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) bf[kk] = *reinterpret_cast<const u32x4*>(tile + (n16 * 16 + li) * MP2_TROW + kk * 32 + lg * 8);
+        for (int kk = 0; kk < KS; ++kk) bf[kk] = tile_l[kk][n16 * 256];
+      };
+      auto mma = [&](const u32x4 (&bf)[KS], f32x4 (&acc)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk) acc[t] = Mfma<T>::run(af[t][kk], bf[kk], acc[t]);
+        }
+      };
+      auto keys = [&](const f32x4 (&acc)[2], int n16, bool tail) {
         const uint32_t colkey = 0xffffu - (uint32_t)(n16 * 16 + li);
         const bool valid = !tail || li < ntail;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kk = 0; kk < KS; ++kk) acc = Mfma<T>::run(af[t][kk], bf[kk], acc);
-          const uint32_t p01 = round_pack2<T>(acc[0], acc[1]), p23 = round_pack2<T>(acc[2], acc[3]);   // similarities in the model dtype (:150)
+          const uint32_t p01 = round_pack2<T>(acc[t][0], acc[t][1]), p23 = round_pack2<T>(acc[t][2], acc[t][3]);   // similarities in the model dtype (:150)
           int k0 = (int)((p01 << 16) | colkey), k1 = (int)((p01 & 0xffff0000u) | colkey);
           int k2 = (int)((p23 << 16) | colkey), k3 = (int)((p23 & 0xffff0000u) | colkey);
           if (tail) {
@@ -443,8 +526,26 @@ __global__ __launch_bounds__(256) void merge_pivot2_kernel(MergeParams p, int ns
           best[t][2] = max(best[t][2], k2); best[t][3] = max(best[t][3], k3);
         }
       };
-      for (int n16 = 0; n16 < nfull; ++n16) tile16(n16, false);
-      if (ntail) tile16(nfull, true);
+      const int ntile = nfull + (ntail ? 1 : 0);                                // >= 1
+      u32x4 bfA[KS], bfB[KS];
+      f32x4 accA[2], accB[2];
+      load_b(bfA, 0);
+      int n16 = 0;
+      for (; n16 + 1 < ntile; n16 += 2) {                                       // tiles n16 (A) and n16 + 1 (B)
+        load_b(bfB, n16 + 1);
+        mma(bfA, accA);
+        if (n16 > 0) keys(accB, n16 - 1, false);
+        if (n16 + 2 < ntile) load_b(bfA, n16 + 2);
+        mma(bfB, accB);
+        keys(accA, n16, false);
+      }
+      if (n16 < ntile) {                                                        // odd tile count: the last tile is in A
+        mma(bfA, accA);
+        if (n16 > 0) keys(accB, n16 - 1, false);
+        keys(accA, n16, ntail != 0);
+      } else {
+        keys(accB, n16 - 1, ntail != 0);
+      }
       bool redo = false;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -465,7 +566,7 @@ __global__ __launch_bounds__(256) void merge_pivot2_kernel(MergeParams p, int ns
       for (int n16 = 0; n16 * 16 < nt; ++n16) {
         u32x4 bf[KS];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) bf[kk] = *reinterpret_cast<const u32x4*>(tile + (n16 * 16 + li) * MP2_TROW + kk * 32 + lg * 8);
+        for (int kk = 0; kk < KS; ++kk) bf[kk] = tile_l[kk][n16 * 256];
         const int col = n16 * 16 + li;
         const uint32_t colkey = col < nt ? 0xffffu - (uint32_t)col : 0xffffffffu;
 #pragma unroll
@@ -493,16 +594,22 @@ __global__ __launch_bounds__(256) void merge_pivot2_kernel(MergeParams p, int ns
 #pragma unroll
         for (int r = 0; r < 4; ++r) res[t][r] = dpp_max16_u32(bestk[t][r]);
     }
-    if (li == 0) {
-      const int rbase = row_wg + s * MP2_HT + wave * 32 + lg * 4;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + t * 16 + r;
-          if (row < n) pivot[row] = (int32_t)(0xffffu - (res[t][r] & 0xffffu));
-        }
+    // every lane of a 16-lane group holds the group's 8 results: lane li = 4 t + r stores pivot (t, r) - one store instruction
+    {
+      const uint32_t r0 = st_t ? res[1][0] : res[0][0], r1 = st_t ? res[1][1] : res[0][1];
+      const uint32_t r2 = st_t ? res[1][2] : res[0][2], r3 = st_t ? res[1][3] : res[0][3];
+      const uint32_t rv = st_r == 0 ? r0 : (st_r == 1 ? r1 : (st_r == 2 ? r2 : r3));
+      const int row = row_wg + s * MP2_HT + wave * 32 + st_t * 16 + lg * 4 + st_r;
+      if (li < 8 && row < n) pivot[row] = (int32_t)(0xffffu - (rv & 0xffffu));
     }
+  };
+  if constexpr (PF == 2) {
+    for (int s = 0; s < nh; s += 2) {
+      stage(s, preA);
+      if (s + 1 < nh) stage(s + 1, preB);
+    }
+  } else {
+    for (int s = 0; s < nh; ++s) stage(s, preA);
   }
 }
 
@@ -512,7 +619,8 @@ __global__ __launch_bounds__(256) void merge_pivot2_kernel(MergeParams p, int ns
 // the atomics produced - the scatter kernel orders every group itself.  More than MB_RANGE kept rows: one pass per range.
 constexpr int MB_RANGE = 8192;
 
-__global__ __launch_bounds__(1024) void merge_bucket_kernel(MergeParams p) {
+__global__ __launch_bounds__(1024) void merge_bucket_kernel(MergeParams p, int fast) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t mb_list[];      // fast path: the head's grouped positions (S <= 32768 entries, 16 bits each)
   __shared__ int32_t cnt[MB_RANGE];
   __shared__ int32_t wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -521,6 +629,50 @@ __global__ __launch_bounds__(1024) void merge_bucket_kernel(MergeParams p) {
   const int32_t* piv = p.pivot + (int64_t)bh * p.S;
   int32_t* list = p.blist + (int64_t)bh * p.S;
   int32_t* start = p.bstart + (int64_t)bh * (nt + 1);
+  if (fast) {                                                             // host: nt * 32 <= MB_RANGE && S <= 32768
+    // the usual size (round 6): every thread keeps its <= 32 pivots and positions in registers (all loads of the kernel leave
+    // together), and every counter exists 32 times - copy (lane & 31) sits in bank (lane & 31), so the 64 atomics of a wave
+    // instruction touch each bank at most twice whatever the pivots are (136 counters shared by 1024 threads serialised:
+    // the one-counter form spent ~10 us per pass at S = 32768).  The scan runs over (kept row, copy) pairs: the rows of a
+    // group land grouped by copy - the scatter kernel orders every group itself.  The placement goes into an LDS copy of
+    // the list (positions fit 16 bits) that is written out with coalesced stores.
+    int pv[32], pos[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) { const int i = u * 1024 + tid; pv[u] = i < n ? piv[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) { const int i = u * 1024 + tid; pos[u] = p.drop[i < n ? i : 0]; }
+    const int cp = lane & 31;
+    for (int j = tid; j < MB_RANGE; j += 1024) cnt[j] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 32; ++u)
+      if ((unsigned)pv[u] < (unsigned)nt) atomicAdd(&cnt[pv[u] * 32 + cp], 1);
+    __syncthreads();
+    int c[8], sum = 0;                                                    // 8 consecutive (row, copy) counters per thread
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { c[e] = cnt[tid * 8 + e]; sum += c[e]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) woff += w2 < wave ? wsum[w2] : 0;
+    int run = woff + incl - sum;
+    if ((tid & 3) == 0 && tid / 4 < nt) start[tid / 4] = run;             // copy 0 of kept row tid / 4: the group's first entry
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cnt[tid * 8 + e] = run; run += c[e]; } // the cursors
+    if (tid == 0) start[nt] = n;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 32; ++u)
+      if ((unsigned)pv[u] < (unsigned)nt) mb_list[atomicAdd(&cnt[pv[u] * 32 + cp], 1)] = (uint16_t)pos[u];
+    __syncthreads();
+    // the grouped list leaves LDS in order: 31k scattered 4-byte stores from one CU took ~13 us, the coalesced copy ~1
+    for (int i = tid; i < n; i += 1024) list[i] = (int32_t)mb_list[i];
+    return;
+  }
   int base = 0;                                                           // rows placed by the earlier ranges
   for (int lo = 0; lo < nt; lo += MB_RANGE) {
     const int hi = min(nt, lo + MB_RANGE);
@@ -681,6 +833,7 @@ __global__ __launch_bounds__(KS * 32) void merge_scatter_kernel(MergeParams p) {
 static int merge_env(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 static int merge_pivot2_on() { static int t = merge_env("PKV_MERGE_PIVOT2", 1); return t; }
 static int merge_pivot2_nst() { static int t = merge_env("PKV_MERGE_NST", 0); return t; }       // 0 = by size
+static int merge_pivot2_pf() { static int t = merge_env("PKV_MERGE_PF", 1); return t; }         // stages of rows in flight per wave
 static int merge_pivot2_nt() { static int t = merge_env("PKV_MERGE_NT", 1); return t; }         // nontemporal row loads
 static int merge_cus() {
   static int cus = 0;
@@ -700,28 +853,39 @@ hipError_t launch_merge_t(const MergeParams& p, hipStream_t st) {
   hipLaunchKernelGGL((merge_targets_kernel<T, KS>), gt, dim3(256), 0, st, p);
   bool pipelined = false;
   if constexpr (KS == 4) {
-    if (nt <= MP2_TN && merge_pivot2_on()) {
-      // stages per workgroup: two rounds of workgroups over the chip's 2-per-CU residency (LDS: 70 KB each), at most 16
-      const int64_t stages = (int64_t)p.B * p.H * ((p.S + MP2_HT - 1) / MP2_HT);
+    if (nt <= MP2_TN && merge_pivot2_on() && p.ks_s > 0 && p.ks_s < (int64_t)1 << 30) {
+      // stages per workgroup: whole rounds of the chip's 3-per-CU residency (LDS: 52 KB each), ~12 stages per workgroup
+      const int64_t sph = (p.S + MP2_HT - 1) / MP2_HT, stages = (int64_t)p.B * p.H * sph, slots = (int64_t)3 * merge_cus();
       int nst = merge_pivot2_nst();
-      if (nst <= 0) nst = (int)std::max<int64_t>(1, std::min<int64_t>(16, stages / (4 * merge_cus())));
-      const dim3 g2((p.S + nst * MP2_HT - 1) / (nst * MP2_HT), p.B * p.H);
-      const size_t lds = 32768 + (size_t)MP2_TN * MP2_TROW * 2;
-      hipError_t e;
-      if (merge_pivot2_nt()) {
-        e = dyn_lds(reinterpret_cast<const void*>(merge_pivot2_kernel<T, true>), lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((merge_pivot2_kernel<T, true>), g2, dim3(256), lds, st, p, nst);
-      } else {
-        e = dyn_lds(reinterpret_cast<const void*>(merge_pivot2_kernel<T, false>), lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((merge_pivot2_kernel<T, false>), g2, dim3(256), lds, st, p, nst);
+      if (nst <= 0) {
+        const int64_t rounds = std::max<int64_t>(1, (stages + slots * 6) / (slots * 12));
+        nst = (int)std::max<int64_t>(1, std::min<int64_t>(sph, (stages + slots * rounds - 1) / (slots * rounds)));
       }
+      const dim3 g2((p.S + nst * MP2_HT - 1) / (nst * MP2_HT), p.B * p.H);
+      const size_t lds = MP2_LDS_BYTES;
+      hipError_t e = hipSuccess;
+#define PKV_MP2(NTL, PFD)                                                                                   \
+  do {                                                                                                      \
+    e = dyn_lds(reinterpret_cast<const void*>(merge_pivot2_kernel<T, NTL, PFD>), lds);                      \
+    if (e != hipSuccess) return e;                                                                          \
+    hipLaunchKernelGGL((merge_pivot2_kernel<T, NTL, PFD>), g2, dim3(256), lds, st, p, nst, (uint32_t)(p.ks_s * 2));                 \
+  } while (0)
+      if (merge_pivot2_pf() == 2) { if (merge_pivot2_nt()) PKV_MP2(true, 2); else PKV_MP2(false, 2); }
+      else                        { if (merge_pivot2_nt()) PKV_MP2(true, 1); else PKV_MP2(false, 1); }
+#undef PKV_MP2
       pipelined = true;
     }
   }
   if (!pipelined) hipLaunchKernelGGL((merge_pivot_kernel<T, KS>), gp, dim3(256), 0, st, p);
-  hipLaunchKernelGGL(merge_bucket_kernel, dim3(p.B * p.H), dim3(1024), 0, st, p);
+  {
+    const int fast = (nt * 32 <= MB_RANGE && p.S <= 32768) ? 1 : 0;
+    const size_t blds = fast ? (size_t)32768 * 2 : 0;
+    if (fast) {
+      const hipError_t eb = dyn_lds(reinterpret_cast<const void*>(merge_bucket_kernel), blds);
+      if (eb != hipSuccess) return eb;
+    }
+    hipLaunchKernelGGL(merge_bucket_kernel, dim3(p.B * p.H), dim3(1024), blds, st, p, fast);
+  }
   hipLaunchKernelGGL((merge_scatter_kernel<T, KS>), gs, dim3(KS * 32), bitmap_bytes, st, p);
   return hipGetLastError();
 }
@@ -911,7 +1075,15 @@ hipError_t launch_merge_f32_t(const MergeParams& p, hipStream_t st) {
   const size_t bitmap_bytes = (size_t)((p.S + 31) / 32) * 4;
   hipLaunchKernelGGL((merge_targets_f32_kernel<KSF>), gt, dim3(256), 0, st, p);
   hipLaunchKernelGGL((merge_pivot_f32_kernel<KSF>), gp, dim3(256), 0, st, p);
-  hipLaunchKernelGGL(merge_bucket_kernel, dim3(p.B * p.H), dim3(1024), 0, st, p);
+  {
+    const int fast = (nt * 32 <= MB_RANGE && p.S <= 32768) ? 1 : 0;
+    const size_t blds = fast ? (size_t)32768 * 2 : 0;
+    if (fast) {
+      const hipError_t eb = dyn_lds(reinterpret_cast<const void*>(merge_bucket_kernel), blds);
+      if (eb != hipSuccess) return eb;
+    }
+    hipLaunchKernelGGL(merge_bucket_kernel, dim3(p.B * p.H), dim3(1024), blds, st, p, fast);
+  }
   hipLaunchKernelGGL((merge_scatter_f32_kernel<D>), gs, dim3(2 * D), bitmap_bytes, st, p);
   return hipGetLastError();
 }
@@ -925,7 +1097,9 @@ hipError_t launch_merge(int dtype, const MergeParams& p, hipStream_t st) {
   const int64_t total = (int64_t)p.B * p.H * p.k;
   const int mb = (int)std::min<int64_t>((total + 255) / 256, 1024);
   hipLaunchKernelGGL(merge_mark_kernel, dim3(mb), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(merge_droplist_kernel, dim3(1), dim3(1024), 0, st, p);
+  static const int droplist2 = merge_env("PKV_MERGE_DROPLIST2", 1);
+  if (droplist2) hipLaunchKernelGGL(merge_droplist2_kernel, dim3((p.S + MD_SLICE - 1) / MD_SLICE), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(merge_droplist_kernel, dim3(1), dim3(1024), 0, st, p);
   if (dtype == 2) return p.D == 64 ? launch_merge_f32_t<4>(p, st) : (p.D == 256 ? launch_merge_f32_t<16>(p, st) : launch_merge_f32_t<8>(p, st));
   if (dtype == 0) {
     if (p.D == 64) return launch_merge_t<BF16, 2>(p, st);
