@@ -301,12 +301,38 @@ __global__ __launch_bounds__(256) void h2o_stats_kernel(H2OParams p) {
       if (lg == 0 && qi[n] < S) rs[qi[n]] = cr[n];
     return false;
   };
-  {
-    if (t_plain > 0) tile_body(0, std::false_type{}, std::true_type{}); else tile_body(0, std::true_type{}, std::true_type{});
+  // Round 6 (the advisor's finding on the round-5 form): a lane's reference point is the maximum of ITS 16 keys of tile 0, and
+  // a row whose maximum lies more than ~88 above it overflows and sends the whole workgroup through the pass again - with
+  // wide logit distributions (large-norm q / k: std >= ~35) that was nearly every workgroup, 2x the pass (19.3 vs 9.2 ms at
+  // S = 32768 with q, k x 8).  A look at the first 16 keys now says how wide the rows are BEFORE the pass starts: 16 samples of
+  // a row with standard deviation s span ~3.5 s, and the row's maximum over 32k keys sits ~2.5 s above the sample's; when
+  // any row of the workgroup spans more than H2O_WIDE (40: s > ~11) the workgroup runs the pass with the TRACKED maximum (the
+  // exact online form, +10 %) right away instead of freezing and repeating.  N(0,1)-like rows (span ~3.5-8, attention sinks
+  // included) never take it; the overflow check and the repeat stay behind the frozen form as the safety net.  The look is 16
+  // MFMAs per wave in its own scope: inside tile 0's body the same four minima cost 20 registers = one wave per SIMD.
+  constexpr float H2O_WIDE = 40.f;
+  bool wide = t_plain == 0;                                                   // the corner mask reaches tile 0: a prompt of a few keys
+  if (!wide) {
+    u32x4 kf[KS];
+    read_frags<KS>(kf, tiles[0], 0, li, lg);
+    f32x4 accs[4];
+    mm16<T, KS>(accs, kf, qf);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float x[4];
+      logits4<T>(accs[n], p, x);
+      float hi = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), lw = fminf(fminf(x[0], x[1]), fminf(x[2], x[3]));
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) { hi = fmaxf(hi, __shfl_xor(hi, o, 64)); lw = fminf(lw, __shfl_xor(lw, o, 64)); }
+      wide |= !(hi - lw <= H2O_WIDE);
+    }
+  }
+  if (!__syncthreads_or(wide)) {
+    tile_body(0, std::false_type{}, std::true_type{});
     for (int t = 1; t < t_plain; ++t) tile_body(t, std::false_type{}, std::false_type{});
     for (int t = t_plain > 1 ? t_plain : 1; t < ntiles; ++t) tile_body(t, std::true_type{}, std::false_type{});
     if (!finish(true)) return;
-    // repeat with the exact online maximum: restage tile 0
+    // a frozen row overflowed after all: repeat with the exact online maximum, tile 0 staged again
     stage_load<KS>(stg, ks, 0);
     stage_store<KS>(stg, tiles[0], tid);
     __syncthreads();
