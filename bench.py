@@ -374,6 +374,7 @@ def main():
         out["config"]["process_group_backend"] = dist.get_backend()
         out["rccl_nranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else None
         out["allgather_us"] = round(ag_us, 1) if ag_us is not None else None      # one all-gather of the whole prefill's indices, alone
+        out.update(first_contact(dist, backend, world, rank, dev, pdist, ks, B, Hl, a))
     # whole-call effective bandwidth: all algorithmic bytes of a call / its wall time
     out["call_effective"] = {"GBps": round(sum(alg.values()) / (ms_per_step / NUM_LAYERS * 1e-3) / 1e9, 1),
                              "frac_of_8TBps": round(sum(alg.values()) / (ms_per_step / NUM_LAYERS * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -417,9 +418,20 @@ def main():
         out["extras"]["merge"] = merge_extra(P, dt, dev, H)
         out["sweep"] = seq_batch_sweep(P, dt, dev, H, alg_bytes)
         out["gpu_eager_baseline"] = gpu_eager_baseline(dt, dev, S, H, cap)
+        # round 6: the same-chip three-way parity block, the real-distribution leg, BASELINE.md section 3's remaining grid rows and
+        # the metric's "prefill tokens/s" on a model with Llama-3-8B's dimensions
+        if not a.no_parity and out.get("parity") is not None:
+            out["parity"]["vs_device_reference"] = three_way_block(P, dev, S, H)
+        out["extras"]["robust"] = robust_extra(P, N, dev, S, H, a)
+        out["extras"]["baseline_grid"] = baseline_grid_extra(P, N, rl, alg_bytes, kernel_rows, a, dev, S, H)
+        out["extras"]["e2e_prefill"] = e2e_prefill_extra(P, N, dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sets = make_sets(1, Hl, S, dt, dev, 1234 + rank, 1)
         out["cpu_baseline"] = cpu_baseline(sets[0], ks, W, cap, a)
+        del sets
+        torch.cuda.empty_cache()
+        if not a.no_extras:
+            out["cpu_baselines_more"] = cpu_baselines_more(P, dev, a)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -892,6 +904,440 @@ def gpu_eager_baseline(dt, dev, S, H, cap):
     return res
 
 
+def first_contact(dist, backend, world, rank, dev, pdist, ks, B, Hl, a):
+    """What the first real multi-GPU run must show before any of its numbers is believed (round-5 review item 8): one distinct
+    device per rank (by PCI bus id, gathered over the process group), the RCCL communicator size == N, the node's xGMI
+    topology as `rocm-smi --showtopo` prints it, and the all-gather's own latency in BOTH exchange modes (one collective per
+    prefill / one per layer).  Raises on a rank / device mismatch: a run that silently shares a GPU is not a measurement."""
+    info = {}
+    try:
+        bus = torch.cuda.get_device_properties(dev).pci_bus_id
+    except Exception:       # noqa: BLE001 - older builds: no bus id on the properties object
+        bus = None
+    ident = "%s/%s/bus%s" % (socket.gethostname(), torch.cuda.get_device_name(dev), bus if bus is not None else "?%d" % dev.index)
+    idents = [None] * world
+    dist.all_gather_object(idents, (rank, dev.index, ident))
+    info["ranks"] = [{"rank": r, "device_index": d, "device": i} for r, d, i in sorted(idents)]
+    distinct = len({(d, i) for _, d, i in idents}) == world
+    info["one_distinct_device_per_rank"] = distinct
+    if backend == "nccl":
+        assert dist.get_world_size() == a.gpus, "RCCL communicator has %d ranks, --gpus %d" % (dist.get_world_size(), a.gpus)
+        assert distinct, "two ranks share a device: %s" % (idents,)
+    # both exchange modes of the selected indices, alone on the device: the whole prefill's buffer once / one layer's indices
+    def timed(fn, n=20):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+    xch = pdist.PrefillIndexExchange(ks, B, Hl, dev, force=True)
+    one = torch.zeros(B, Hl, ks[0], dtype=torch.int32, device=dev)
+    info["allgather_us_by_mode"] = {"prefill (one collective, all 32 layers' indices)": round(timed(lambda: xch.views(xch.gather_async())), 1),
+                                    "layer (one collective per layer, k = %d)" % ks[0]: round(timed(lambda: pdist.allgather_indices_async(one, force=True).wait()), 1)}
+    if rank == 0:
+        try:
+            r = subprocess.run(["rocm-smi", "--showtopo"], capture_output=True, text=True, timeout=20)
+            info["rocm_smi_showtopo"] = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("=")][:80]
+        except Exception as e:      # noqa: BLE001
+            info["rocm_smi_showtopo"] = "unavailable: %s" % e
+    return {"first_contact": info}
+
+
+def three_way_block(P, dev, S, H):
+    """`parity.vs_device_reference` (round-5 review item 1): libpkv vs the reference's op sequence on the host CPU vs the SAME op
+    sequence on PyTorch-ROCm eager on this GPU, on one seeded [1,H,S,128] set in bf16 and fp16, for the budgets of PyramidKV's
+    first / last layer and SnapKV 128 / 2048 (tests/three_way.py; the full grid is profiles/r06/parity_three_way.json).  Per
+    pair: fraction of heads with the identical index set / sequence / K,V bits; against the device reference libpkv runs with
+    scale "rcp" + tie order "aten_rocm" (what ATen's HIP kernels do), against the CPU reference with its defaults."""
+    import three_way as T3
+    from inputs import make_qkv
+    out = {"checker": "tests/three_way.py: oracle/pkv_oracle.py on CPU tensors (cpu) and on HIP tensors (eager = PyTorch-ROCm's own kernels)"}
+    for dname in ("bf16", "fp16"):
+        q, k, v = make_qkv(1, H, S, D, dname, "gauss", 6300)
+        rep = T3.window_policy(P, q, k, v, W, {"pyramid_layer0_k234": 234, "pyramid_layer31_k17": 17, "snapkv_budget128": 120,
+                                               "snapkv_budget2048": 2040}, dev=dev)
+        out[dname] = T3.summarise(rep)
+        b = rep["budgets"]["snapkv_budget2048"]
+        out[dname]["budget2048_heads_in_another_order"] = {p_: b[p_]["heads"] - b[p_]["identical_sequence"]
+                                                           for p_ in ("hip_vs_cpu", "hip_vs_eager", "eager_vs_cpu")}
+    return out
+
+
+def _call_us(fn, sets, iters=10, reps=3):
+    """device time per call between two events around `iters` back-to-back calls, fastest of `reps` rounds (one host hiccup -
+    a page fault, an allocator refill - inside a 10-call window otherwise shows up as milliseconds)"""
+    for it in range(3):
+        fn(*sets[it % len(sets)])
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for it in range(iters):
+            fn(*sets[it % len(sets)])
+        ev1.record()
+        torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) / iters * 1e3
+        best = us if best is None or us < best else best
+    return best
+
+
+def _kernel_us(N, fn, sets, iters=10):
+    N.prof_enable(True)
+    N.prof_read(reset=True)
+    for it in range(iters):
+        fn(*sets[it % len(sets)])
+    torch.cuda.synchronize()
+    prof = N.prof_read(reset=True)
+    N.prof_enable(False)
+    return {k_: round(v_[0] / v_[1] * 1e3, 2) for k_, v_ in prof.items() if v_[1]}
+
+
+def _sel_parity(P, q, k, v, w, kk, pooling, ksz, idx, kc, vc):
+    """heads with the oracle's index set / sequence / K,V bits for one dense selection (canonical tie order)."""
+    from oracle import pkv_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    qc, kc_, vc_ = q[:1].cpu(), k[:1].cpu(), v[:1].cpu()
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = O.pool_scores(O.window_scores(qc, kc_, w), pooling, ksz)
+    ridx = O.topk_canonical(s, kk)
+    kr, vr = O.gather_compact(kc_, vc_, ridx, w)
+    ia = idx[:1].cpu().long()
+    kth = torch.gather(s, -1, ridx[..., kk - 1:kk])
+    return {"heads_identical_set": float((torch.sort(ia, -1).values == torch.sort(ridx, -1).values).all(-1).float().mean()),
+            "heads_identical_sequence": float((ia == ridx).all(-1).float().mean()),
+            "kv_bit_identical_heads": float(((kc[:1].cpu() == kr).flatten(2).all(-1) & (vc[:1].cpu() == vr).flatten(2).all(-1)).float().mean()),
+            "ties_at_kth_value_mean": float((s == kth).sum(-1).float().mean())}
+
+
+def robust_extra(P, N, dev, S, H, a):
+    """Real-distribution leg (round-5 review item 5; not `value`): the same calls on `make_qkv(kind="sink")` inputs in fp16 -
+    logits with std 6 and an attention-sink key every window query scores at +40, so that all but a few hundred pooled scores
+    per head underflow to exactly 0 and the k-th largest value is tied tens of thousands of times (topk_kernel leaves its
+    small-k prefilter for the general path, pkv_topk.hip "heavy ties") - next to the same calls on fp16 N(0,1) inputs: wall
+    time per call, device time per kernel, the sink / gauss ratio, and a parity block against the CPU oracle.  H2O: both passes
+    on sink data at S (pass 1 decides tracked vs frozen from a 16-key look, pkv_h2o.hip) and parity at S = 8192 on 4 heads."""
+    from inputs import make_qkv
+    from oracle import pkv_oracle as O
+    res = {"inputs": "tests/inputs.py make_qkv(kind='sink'): fp16, [1,%d,%d,128], logit std 6, sink key at position 0 scored +40 by the last 64 queries" % (H, S)}
+    legs = {}
+    for kind in ("gauss", "sink"):
+        q, k, v = (t.to(dev) for t in make_qkv(1, H, S, D, "fp16", kind, 6600))
+        sets = [(q, k, v)]
+        row = {}
+        for cap in (128, 2048):
+            kk = cap - W
+            fn = lambda q_, k_, v_: P.ops.compress(q_, k_, v_, W, kk, "maxpool", 7)       # noqa: E731
+            r = {"update_kv_us": round(_call_us(fn, sets), 2), "kernels_us": _kernel_us(N, fn, sets)}
+            if kind == "sink" and not a.no_parity:
+                kc, vc, idx = P.ops.compress(q, k, v, W, kk, "maxpool", 7, return_indices=True)
+                r["parity"] = _sel_parity(P, q, k, v, W, kk, "maxpool", 7, idx, kc, vc)
+            row["snapkv_budget%d" % cap] = r
+        fn = lambda q_, k_, v_: P.ops.score_h2o(q_, k_, W)                                # noqa: E731
+        ku = _kernel_us(N, fn, sets, iters=3)
+        row["h2o_scores"] = {"stats_ms": round(ku.get("h2o_stats", 0) / 1e3, 3), "colsum_ms": round(ku.get("h2o_colsum", 0) / 1e3, 3)}
+        legs[kind] = row
+        del q, k, v, sets
+        torch.cuda.empty_cache()
+    res.update(legs)
+    res["sink_over_gauss"] = {
+        "snapkv_budget128": round(legs["sink"]["snapkv_budget128"]["update_kv_us"] / legs["gauss"]["snapkv_budget128"]["update_kv_us"], 3),
+        "snapkv_budget2048": round(legs["sink"]["snapkv_budget2048"]["update_kv_us"] / legs["gauss"]["snapkv_budget2048"]["update_kv_us"], 3),
+        "topk_kernel_budget2048": round(legs["sink"]["snapkv_budget2048"]["kernels_us"].get("topk", 0) / max(1e-9, legs["gauss"]["snapkv_budget2048"]["kernels_us"].get("topk", 0)), 3),
+        "h2o_scores": round((legs["sink"]["h2o_scores"]["stats_ms"] + legs["sink"]["h2o_scores"]["colsum_ms"])
+                            / max(1e-9, legs["gauss"]["h2o_scores"]["stats_ms"] + legs["gauss"]["h2o_scores"]["colsum_ms"]), 3)}
+    if not a.no_parity:                      # H2O on sink data against the materialised S x S oracle: S = 8192, 4 heads
+        q, k, v = make_qkv(1, 4, 8192, D, "fp16", "sink", 6601)
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        want = O.h2o_scores_blocked(q, k, W, block=512)
+        got = P.ops.score_h2o(q.to(dev), k.to(dev), W).cpu()
+        b_g, b_w = (t.view(torch.int16).int() & 0xffff for t in (got, want))
+        d_ = (torch.where(b_g >= 0x8000, -(b_g & 0x7fff), b_g) - torch.where(b_w >= 0x8000, -(b_w & 0x7fff), b_w)).abs()
+        kc, vc, idx = P.ops.compress(q.to(dev), k.to(dev), v.to(dev), W, 120, None, 1, h2o=True, return_indices=True)
+        ridx = O.topk_canonical(want, 120)
+        normal = want.float().abs() >= 2.0 ** -14           # below it fp16 is subnormal: one "ulp" is the absolute step 2^-24, and every
+        #                                                        probability that flips between 0 and 2^-24 moves the column sum by one step
+        res["h2o_parity_S8192_4heads"] = {"score_mismatch_frac": round(float((d_ > 0).float().mean()), 7), "score_max_ulp": int(d_.max()),
+                                         "score_max_ulp_normal_range": int(d_[normal].max()) if bool(normal.any()) else 0,
+                                         "scores_in_subnormal_range_frac": round(float((~normal).float().mean()), 4),
+                                         "heads_identical_set_budget128": float((torch.sort(idx.cpu().long(), -1).values == torch.sort(ridx, -1).values).all(-1).float().mean())}
+    return res
+
+
+def baseline_grid_extra(P, N, rl, alg_bytes, kernel_rows, a, dev, S, H):
+    """BASELINE.md section 3's grid rows the headline / `grid` / `sweep` do not carry (round-5 review item 6; not `value`): the
+    fp16 twin of the headline step (every reference runner's dtype, run_longbench.py:388), the `init_*` default knobs
+    (window 32, avgpool-5, pyramidkv_utils.py:885-890), budget 64 (BASELINE config 1's budget), and StreamingLLM - each as one
+    timed workload with per-kernel device time and a parity block."""
+    res = {}
+    f16 = torch.float16
+    # fp16 twin of the headline: 32 PyramidKV layer budgets, 4 rotating sets
+    ks = layer_budgets(P, "pyramidkv", 128, W, S)
+    clusters = make_clusters(P, "pyramidkv", 128)
+    sets = make_sets(1, H, S, f16, dev, 4242, 4)
+    slots = [torch.empty(1, H, ks[layer], dtype=torch.int32, device=dev) for layer in range(NUM_LAYERS)]
+
+    def step(keep=None):
+        for layer in range(NUM_LAYERS):
+            q, k, v = sets[layer % len(sets)]
+            cl = clusters[layer]
+            cl.index_out = slots[layer]
+            kc, vc = cl.update_kv(k, q, v, None, 1)
+            if keep is not None and layer in keep:
+                keep[layer] = (kc, vc, slots[layer].clone())
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    steps = max(5, a.steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    N.prof_enable(True)
+    N.prof_read(reset=True)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    prof = N.prof_read(reset=True)
+    N.prof_enable(False)
+    rows = kernel_rows(prof, alg_bytes(1, H, S, sum(ks) / NUM_LAYERS))
+    row = {"workload": "pyramidkv budget=128 window=8 maxpool7, 32 update_kv calls/step, [1,%d,%d,128] fp16" % (H, S),
+           "ms_per_step": round(el / steps * 1e3, 4), "tokens_per_s": round(S * steps / el, 1),
+           "kernels_us": {k_: r["avg_us"] for k_, r in rows.items()}, "roofline": rows.get("logits")}
+    if not a.no_parity:
+        keep = {0: None, NUM_LAYERS - 1: None}
+        step(keep)
+        torch.cuda.synchronize()
+        row["parity"] = parity_block_for(keep, sets, ks, 128, "pyramidkv", "fp16", S)
+    res["headline_fp16"] = row
+    del sets, slots
+    torch.cuda.empty_cache()
+
+    # the init_* defaults (window 32, avgpool-5) and budget 64, bf16, one SnapKV call each; StreamingLLM (no scoring)
+    bf = torch.bfloat16
+    sets = make_sets(1, H, S, bf, dev, 4343, 2)
+    for name, w_, cap, pool, ksz in (("init_defaults_window32_avgpool5_budget128", 32, 128, "avgpool", 5),
+                                     ("init_defaults_window32_avgpool5_budget2048", 32, 2048, "avgpool", 5),
+                                     ("budget64_window8_maxpool7", 8, 64, "maxpool", 7)):
+        cl = P.SnapKVCluster(window_size=w_, max_capacity_prompt=cap, kernel_size=ksz, pooling=pool)
+        fn = lambda q_, k_, v_: cl.update_kv(k_, q_, v_, None, 1)                        # noqa: E731
+        us = _call_us(fn, sets)
+        r = {"policy": "snapkv", "window": w_, "budget": cap, "pooling": "%s-%d" % (pool, ksz), "S": S, "dtype": "bf16",
+             "update_kv_us": round(us, 2), "tokens_per_s": round(S / us * 1e6, 0), "kernels_us": _kernel_us(N, fn, sets)}
+        if not a.no_parity:
+            q, k, v = sets[0]
+            kc, vc, idx = P.ops.compress(q, k, v, w_, cap - w_, pool, ksz, return_indices=True)
+            r["parity"] = _sel_parity(P, q, k, v, w_, cap - w_, pool, ksz, idx, kc, vc)
+        res[name] = r
+    # PyramidKV budget 64: the 32 layer budgets 110 ... 17 of BASELINE config 1 at the headline length
+    ks64 = layer_budgets(P, "pyramidkv", 64, W, S)
+    cl64 = [P.PyramidKVCluster(num_hidden_layers=NUM_LAYERS, layer_idx=layer, window_size=W, max_capacity_prompt=64, kernel_size=7, pooling="maxpool")
+            for layer in range(NUM_LAYERS)]
+
+    def step64():
+        for layer in range(NUM_LAYERS):
+            q, k, v = sets[layer % len(sets)]
+            cl64[layer].update_kv(k, q, v, None, 1)
+    for _ in range(2):
+        step64()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step64()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    res["pyramidkv_budget64"] = {"layer_budgets": "%d ... %d" % (ks64[0], ks64[-1]), "ms_per_step": round(el / steps * 1e3, 4),
+                                 "tokens_per_s": round(S * steps / el, 1)}
+    st = P.StreamingLLMKVCluster(window_size=124, max_capacity_prompt=128)              # the runners' w = cap - 4 (run_longbench.py:222-223)
+    us = _call_us(lambda q_, k_, v_: st.update_kv(k_, q_, v_, None, 1), sets)
+    res["streamingllm_budget128"] = {"update_kv_us": round(us, 2), "tokens_per_s": round(S / us * 1e6, 0)}
+    del sets
+    torch.cuda.empty_cache()
+    return res
+
+
+def e2e_prefill_extra(P, N, dev):
+    """The metric's "prefill tokens/s" on a model with Llama-3-8B's dimensions (round-5 review item 4; not `value`): random-init
+    LlamaForCausalLM, 32 layers, hidden 4096, 32 / 8 heads, D = 128, intermediate 14336, bf16, small vocabulary (no weights on
+    disk), prefill of one sequence through `replace_llama("pyramidkv")` (budget 128, window 8, maxpool-7) at S = 8192 and
+    32768: tokens/s with eviction OFF (the stock attention), ON in the reference's order (repeat_kv first, llama_model.py:158-168)
+    and ON with K/V handed over before repeat_kv; `update_kv_share` = the 32 update_kv calls' kernel time / the prefill's wall
+    time.  The attention itself is PyTorch SDPA: the model is the caller of this path, not part of it."""
+    try:
+        from transformers import LlamaConfig, LlamaForCausalLM, DynamicCache
+    except Exception as e:      # noqa: BLE001
+        return {"skipped": "transformers unavailable: %s" % e}
+    from pyramidkv_amd import monkeypatch as mp
+    cfg = LlamaConfig(vocab_size=1024, hidden_size=4096, intermediate_size=14336, num_hidden_layers=NUM_LAYERS, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, max_position_embeddings=65536, rope_theta=500000.0)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        with torch.device(dev):
+            model = LlamaForCausalLM(cfg).eval()
+    finally:
+        torch.set_default_dtype(old)
+    res = {"model": "random-init Llama, Llama-3-8B dimensions (32 layers, hidden 4096, 32/8 heads, D 128, MLP 14336), bf16, vocab 1024, SDPA attention",
+           "policy": "pyramidkv budget=128 window=8 maxpool7"}
+
+    def prefill(ids):
+        with torch.no_grad():
+            model(ids, past_key_values=DynamicCache(config=cfg), use_cache=True, logits_to_keep=1)
+
+    def timed(ids, n=2):
+        prefill(ids)
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            prefill(ids)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            best = t if best is None or t < best else best
+        return best
+    try:
+        for S in (8192, 32768):
+            ids = torch.randint(0, 1024, (1, S), device=dev)
+            row = {}
+            t_off = timed(ids)
+            row["eviction_off"] = {"prefill_ms": round(t_off * 1e3, 2), "tokens_per_s": round(S / t_off, 0)}
+            for label, skip in (("eviction_on_reference_order", False), ("eviction_on_skip_repeat_kv", True)):
+                mp.replace_llama("pyramidkv")
+                mp.skip_repeat_kv = skip
+                for layer in model.model.layers:
+                    c = layer.self_attn.config
+                    c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.merge = W, 128, 7, "maxpool", None
+                t_on = timed(ids)
+                N.prof_enable(True)
+                N.prof_read(reset=True)
+                prefill(ids)
+                torch.cuda.synchronize()
+                prof = N.prof_read(reset=True)
+                N.prof_enable(False)
+                kms = sum(v_[0] for v_ in prof.values())
+                row[label] = {"prefill_ms": round(t_on * 1e3, 2), "tokens_per_s": round(S / t_on, 0),
+                              "update_kv_kernels_ms_all_32_layers": round(kms, 3), "update_kv_share": round(kms / (t_on * 1e3), 5),
+                              "vs_eviction_off": round(t_on / t_off, 4)}
+                mp.restore()
+            res["S%d" % S] = row
+            del ids
+    finally:
+        mp.skip_repeat_kv = True
+        mp.restore()
+        del model
+        torch.cuda.empty_cache()
+    return res
+
+
+_REF = {}
+
+
+def reference_module():
+    """pyramidkv/pyramidkv_utils.py of the real reference, imported when /root/reference exists on this box (the build
+    container; never the GPU boxes) - BASELINE.md section 3: "imported when present, else the restatement"."""
+    if "mod" not in _REF:
+        mod = None
+        ref = os.environ.get("PKV_REFERENCE_ROOT", "/root/reference")
+        if os.path.exists(os.path.join(ref, "pyramidkv", "pyramidkv_utils.py")):
+            try:
+                sys.path.insert(0, ref)
+                import importlib
+                mod = importlib.import_module("pyramidkv.pyramidkv_utils")
+            except Exception:       # noqa: BLE001 - an unusable checkout is the same as none
+                mod = None
+        _REF["mod"] = mod
+    return _REF["mod"]
+
+
+def _cpu_time(fn, seconds):
+    """best and median of up to 5 timed calls after one warm-up, bounded by ~`seconds` of CPU work"""
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        fn()
+        first = time.perf_counter() - t0
+        ts = []
+        while len(ts) < 5 and (sum(ts) + first < seconds or len(ts) < 1):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[0], ts[len(ts) // 2], len(ts)
+
+
+def cpu_baselines_more(P, dev, a):
+    """Time-boxed host-core baselines for the BASELINE configurations other than the headline (round-5 review item 6): SnapKV
+    budget 2048 at S = 32768, H2O at S = 4096 (the largest the unmodified reference runs: it materialises S x S) and Ada-SnapKV at
+    S = 8192 - the reference's own update_kv when /root/reference is on this box (`kind: "reference"`), else the bit-pinned
+    restatement (`"port"`) - each next to the same call through libpkv on this GPU."""
+    from oracle import pkv_oracle as O
+    from inputs import make_qkv
+    ref = reference_module()
+    ncpu = os.cpu_count() or 1
+    nt = min(ncpu, 64)
+    torch.set_num_threads(nt)
+    kind = "reference" if ref is not None else "port"
+    out = {"kind": kind, "cores": nt, "host_logical_cpus": ncpu,
+           "what": ("pyramidkv/pyramidkv_utils.py imported from /root/reference" if ref is not None else
+                    "oracle/pkv_oracle.py (== the reference bit for bit on the committed fixtures)") + ", torch.set_num_threads(%d), stdout suppressed" % nt}
+    dname = a.dtype
+
+    def gpu_us(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 5 * 1e6
+    # SnapKV budget 2048, S = 32768
+    q, k, v = make_qkv(1, 32, 32768, D, dname, "gauss", 1234)
+    if ref is not None:
+        cl = ref.SnapKVCluster(window_size=W, max_capacity_prompt=2048, kernel_size=7, pooling="maxpool")
+        f = lambda: cl.update_kv(k, q, v, None, 1)                                           # noqa: E731
+    else:
+        f = lambda: O.snapkv_update_kv(k, q, v, W, 2048, 7, "maxpool", topk_mode="reference")  # noqa: E731
+    best, med, n = _cpu_time(f, a.cpu_seconds / 3)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    hcl = P.SnapKVCluster(window_size=W, max_capacity_prompt=2048, kernel_size=7, pooling="maxpool")
+    out["snapkv_budget2048_S32768"] = {"cpu_ms": round(best * 1e3, 2), "cpu_ms_median": round(med * 1e3, 2), "calls": n, "cpu_tokens_per_s": round(32768 / best, 0),
+                                       "libpkv_us": round(gpu_us(lambda: hcl.update_kv(kd, qd, vd, None, 1)), 2)}
+    # H2O, S = 4096
+    q, k, v = make_qkv(1, 32, 4096, D, dname, "gauss", 1235)
+    if ref is not None:
+        cl = ref.H2OKVCluster(window_size=W, max_capacity_prompt=128, kernel_size=7, pooling="maxpool")
+        f = lambda: cl.update_kv(k, q, v, None, 1)                                           # noqa: E731
+    else:
+        f = lambda: O.h2o_update_kv(k, q, v, W, 128, topk_mode="reference")                  # noqa: E731
+    best, med, n = _cpu_time(f, a.cpu_seconds / 3)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    hcl = P.H2OKVCluster(window_size=W, max_capacity_prompt=128, kernel_size=7, pooling="maxpool")
+    out["h2o_budget128_S4096"] = {"cpu_ms": round(best * 1e3, 2), "cpu_ms_median": round(med * 1e3, 2), "calls": n, "cpu_tokens_per_s": round(4096 / best, 0),
+                                  "libpkv_us": round(gpu_us(lambda: hcl.update_kv(kd, qd, vd, None, 1)), 2),
+                                  "note": "the largest S the unmodified reference runs: it materialises [1,32,S,S] (:544,553)"}
+    # Ada-SnapKV, S = 8192 (floor 0.2, normalize; K/V expanded as the reference receives them)
+    q, k, v = make_qkv(1, 32, 8192, D, dname, "gauss", 1236)
+    if ref is not None:
+        cl = ref.AdaKVCluster(window_size=W, kernel_size=7, pooling="maxpool", max_capacity_prompt=128, floor=0.2, normalize=True,
+                              layer_idx=0, num_hidden_layers=NUM_LAYERS)
+        f = lambda: cl.update_kv(k, q, v)                                                    # noqa: E731
+    else:
+        f = lambda: O.adakv_update_kv(k, q, v, W, 128, 7, "maxpool", 0.2, True, sort_mode="reference")   # noqa: E731
+    best, med, n = _cpu_time(f, a.cpu_seconds / 3)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    hcl = P.AdaKVCluster(window_size=W, kernel_size=7, pooling="maxpool", max_capacity_prompt=128, floor=0.2, normalize=True,
+                         layer_idx=0, num_hidden_layers=NUM_LAYERS)
+    out["adakv_budget128_S8192"] = {"cpu_ms": round(best * 1e3, 2), "cpu_ms_median": round(med * 1e3, 2), "calls": n, "cpu_tokens_per_s": round(8192 / best, 0),
+                                    "libpkv_us": round(gpu_us(lambda: hcl.update_kv(kd, qd, vd)), 2)}
+    return out
+
+
+
 def cpu_baseline(qkv, ks, w, cap, a):
     """The reference's eager path (oracle restatement == pyramidkv_utils.py:197-283 executed by PyTorch CPU) on
     the host cores of this node, same tensors moved to the CPU.  Bounded sample: a few of the 32 layer-calls,
@@ -903,11 +1349,20 @@ def cpu_baseline(qkv, ks, w, cap, a):
     n = max(1, min(a.cpu_layers, NUM_LAYERS))
     layers = [round(i * (NUM_LAYERS - 1) / max(1, n - 1)) for i in range(n)] if n > 1 else [0]
 
+    ref = reference_module()           # the reference's own file when this box has it, else the restatement
+    ref_clusters = None
+    if ref is not None:
+        ref_clusters = [ref.PyramidKVCluster(num_hidden_layers=NUM_LAYERS, layer_idx=layer, window_size=w, max_capacity_prompt=cap, kernel_size=7,
+                                             pooling="maxpool") if a.policy == "pyramidkv" else
+                        ref.SnapKVCluster(window_size=w, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool") for layer in range(NUM_LAYERS)]
+
     def run(ls):
         t0 = time.perf_counter()
         for layer in ls:
             with contextlib.redirect_stdout(io.StringIO()):
-                if a.policy == "pyramidkv":
+                if ref_clusters is not None:
+                    ref_clusters[layer].update_kv(k, q, v, None, 1)
+                elif a.policy == "pyramidkv":
                     O.pyramidkv_update_kv(k, q, v, w, cap, 7, "maxpool", NUM_LAYERS, layer, topk_mode="reference")
                 else:
                     O.snapkv_update_kv(k, q, v, w, cap, 7, "maxpool", topk_mode="reference")
@@ -939,7 +1394,8 @@ def cpu_baseline(qkv, ks, w, cap, a):
         pass
     gold = os.path.join(ROOT, "tests", "golden", "index.json")
     nfix = len(json.load(open(gold)).get("cases", [])) if os.path.exists(gold) else 0
-    return {"value": round(S * len(layers) / NUM_LAYERS / t, 1), "unit": "tokens/s", "cores": best_n, "kind": "port",
+    return {"value": round(S * len(layers) / NUM_LAYERS / t, 1), "unit": "tokens/s", "cores": best_n, "kind": "reference" if ref is not None else "port",
+            "reference_file": "/root/reference/pyramidkv/pyramidkv_utils.py (imported)" if ref is not None else "absent on this box: the bit-pinned restatement runs instead",
             "port_checked_against": "oracle/pkv_oracle.py == the real reference (pyramidkv/pyramidkv_utils.py, imported) bit-for-bit on "
                                     "%d committed fixtures (tests/golden/, tests/test_oracle_golden.py)" % nfix,
             "sample": "%d of the 32 layer-calls per pass (layers %s) of the same workload ([1,%d,%d,128] %s), %d passes = %.1f s "

@@ -291,6 +291,10 @@ PKV_API int pkv_debug_wg_trace(void* device_u64);     /* NULL disables; 2*262144
  * that the suite checks the shipped code, not a copy.  Nothing on the product path launches them (~2 KB of code). */
 PKV_API int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream);
 PKV_API int pkv_debug_round(int32_t dtype, const float* in, void* out, int64_t n, pkv_stream_t stream);
+/* Host-only: the fp32 constant the bf16 / fp16 kernels multiply a logit by in place of "/ math.sqrt(head_dim)"
+ * (pyramidkv_utils.py:317) for this dtype, head size and pkv_scale mode; tests/test_abi_and_host.py checks, over every finite
+ * 16-bit input, that the multiply reproduces ATen's division ("div") / reciprocal multiply ("rcp") bit for bit. */
+PKV_API float pkv_debug_scale_multiplier(int32_t dtype, int32_t D, int32_t scale_mode);
 
 #ifdef __cplusplus
 }

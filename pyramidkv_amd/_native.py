@@ -95,6 +95,7 @@ def _load():
         "pkv_debug_wg_trace": (C.c_int, [vp]),
         "pkv_debug_exp": (C.c_int, [vp, vp, i64, vp]),
         "pkv_debug_round": (C.c_int, [i32, vp, vp, i64, vp]),
+        "pkv_debug_scale_multiplier": (C.c_float, [i32, i32, i32]),
         "pkv_prof_enable": (C.c_int, [C.c_int]),
         "pkv_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     }

@@ -49,6 +49,14 @@ int gather_rpt() { static int t = env_int("PKV_GATHER_RPT", 0); return t; }   //
 int gather_xcd() { static int t = env_int("PKV_GATHER_XCD", 0); return t; }
 
 inline int hip_fail(hipError_t e) { g_last_hip = (int)e; return PKV_ERR_HIP; }
+
+// the constant the 16-bit kernels multiply a logit by instead of dividing it by fp32(sqrt(head_dim)) - pkv_common.hpp scale_logit
+float scale_multiplier(int dtype, int D, int scale_mode) {
+  const float c = (float)sqrt((double)D);                  // math.sqrt(head_dim), cast to the fp32 opmath type
+  float rc = 1.0f / c;                                     // ATen GPU path: a * (1.0f / b)
+  if (dtype == PKV_F16 && scale_mode == PKV_SCALE_DIV && D == 128) rc = nextafterf(rc, 1.0f);   // == the fp32 division for every finite fp16 input
+  return rc;
+}
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 
@@ -183,7 +191,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   lp.ks_b = d->k_stride[0]; lp.ks_h = d->k_stride[1]; lp.ks_s = d->k_stride[2];
   lp.scale_mode = d->scale_mode;
   lp.sqrt_d = (float)sqrt((double)d->D);   // math.sqrt(head_dim), cast to the fp32 opmath type
-  lp.rcp_sqrt_d = 1.0f / lp.sqrt_d;        // ATen GPU path: a * (1.0f / b)
+  lp.rcp_sqrt_d = d->dtype == PKV_F32 ? 1.0f / lp.sqrt_d : scale_multiplier(d->dtype, d->D, d->scale_mode);
   const int C = d->kv_group * d->window;
   int nT_used = L.nT;
   if (d->dtype == PKV_F32) {
@@ -277,7 +285,7 @@ int do_score_h2o(const pkv_desc* d, const void* q, const void* k, void* scores, 
   hp.ks_b = d->k_stride[0]; hp.ks_h = d->k_stride[1]; hp.ks_s = d->k_stride[2];
   hp.scale_mode = d->scale_mode;
   hp.sqrt_d = (float)sqrt((double)d->D);
-  hp.rcp_sqrt_d = 1.0f / hp.sqrt_d;
+  hp.rcp_sqrt_d = d->dtype == PKV_F32 ? 1.0f / hp.sqrt_d : scale_multiplier(d->dtype, d->D, d->scale_mode);
   if (d->dtype == PKV_F32) {                                                 // both passes of the fp32 form (pkv_f32.hip)
     ProfScope ps(PKV_K_H2O_COLSUM, st);
     hipError_t e = launch_h2o_f32(hp, st);
@@ -825,6 +833,8 @@ int pkv_debug_topk_trace(void* device_u64x8) { return device_u64x8 ? PKV_ERR_UNS
 int pkv_debug_wg_trace(void* device_u64) { return device_u64 ? PKV_ERR_UNSUPPORTED : PKV_OK; }
 int pkv_debug_build(void) { return 0; }
 #endif
+
+float pkv_debug_scale_multiplier(int32_t dtype, int32_t D, int32_t scale_mode) { return scale_multiplier(dtype, D, scale_mode); }
 
 int pkv_debug_exp(const float* in, float* out, int64_t n, pkv_stream_t stream) {
   hipError_t e = launch_debug_exp(in, out, n, static_cast<hipStream_t>(stream));

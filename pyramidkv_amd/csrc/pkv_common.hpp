@@ -138,16 +138,15 @@ __device__ __forceinline__ float div_const(float x, float c, float rc) {
   return fmaf(r, rc, q);
 }
 
-// "attn / math.sqrt(head_dim)" (reference pyramidkv_utils.py:317) on a value already rounded to the model
-// dtype, result about to be rounded to the model dtype again.  head_dim is 128 in this build, and for
-// bf16 round(x / sqrt(128)) == round(x * fp32(1/sqrt(128))) for EVERY finite bf16 x (exhaustive check in
-// tests/test_abi_and_host.py), so both scale modes use the one-instruction multiply.  fp16 has 52 inputs
-// where the two differ: "div" mode keeps the correctly rounded division there.
-template <typename T> __device__ __forceinline__ float scale_logit(float x, int scale_mode, float c, float rc);
-template <> __device__ __forceinline__ float scale_logit<BF16>(float x, int, float, float rc) { return x * rc; }
-template <> __device__ __forceinline__ float scale_logit<F16>(float x, int scale_mode, float c, float rc) {
-  return scale_mode == 0 ? div_const(x, c, rc) : x * rc;
-}
+// "attn / math.sqrt(head_dim)" (reference pyramidkv_utils.py:317) on a value already rounded to the model dtype, result
+// about to be rounded to the model dtype again: ONE multiply by a host-chosen constant `rc` in both scale modes
+// (pkv_api.hip scale_multiplier; exhaustive checks over every finite 16-bit input in tests/test_abi_and_host.py):
+//   head_dim 64 / 256: the divisor is a power of two, rc = 1/8, 1/16 is the division;
+//   head_dim 128, bf16: round(x / fp32(sqrt(128))) == round(x * fp32(1/sqrt(128))) for EVERY finite bf16 x;
+//   head_dim 128, fp16: that constant differs from the division on 52 inputs, its fp32 NEIGHBOUR ABOVE on none (round 6; the
+//     "div" mode used to take a correctly rounded division, 3 instructions per logit - +40 % on the fp16 H2O pair) - so "div"
+//     multiplies by nextafter(fp32(1/sqrt(128)), 1) and "rcp" (what ATen's HIP kernels do) by fp32(1/sqrt(128)).
+template <typename T> __device__ __forceinline__ float scale_logit(float x, int, float, float rc) { return x * rc; }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

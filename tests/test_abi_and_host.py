@@ -311,22 +311,31 @@ def test_missing_extension_fails_loudly(tmp_path, monkeypatch):
     importlib.reload(N)
 
 
-def test_bf16_scale_by_reciprocal_equals_division_exhaustively():
-    """csrc/pkv_common.hpp scale_logit<BF16>: for head_dim 128, round_bf16(x / sqrt(128)) ==
-    round_bf16(x * fp32(1/sqrt(128))) for EVERY finite bf16 x, so the kernels may multiply in both scale
-    modes; fp16 does have exceptions, which is why it keeps the exact division in "div" mode."""
+def test_scale_multiplier_equals_division_exhaustively(P):
+    """csrc/pkv_common.hpp scale_logit: the 16-bit kernels multiply a logit by ONE fp32 constant instead of dividing it by
+    fp32(sqrt(head_dim)) (pyramidkv_utils.py:317).  For every dtype, head size and scale mode the constant the library uses
+    (pkv_debug_scale_multiplier) must reproduce, for EVERY finite 16-bit input, round_dtype(x / fp32(sqrt(D))) in "div" mode (ATen
+    CPU) and round_dtype(x * fp32(1 / fp32(sqrt(D)))) in "rcp" mode (ATen's HIP kernels).  bf16: the plain reciprocal does
+    both; fp16 at D = 128: the reciprocal differs from the division on 52 inputs, its fp32 neighbour above on none."""
     import math
     import numpy as np
-    c32 = np.float32(math.sqrt(128.0))
-    rc = float(np.float32(1.0) / c32)
+    N = P._native
     bits16 = torch.arange(65536, dtype=torch.int32).to(torch.int16)
-    for tdt, expect_equal in ((torch.bfloat16, True), (torch.float16, False)):
+    for tdt, code in ((torch.bfloat16, N.PKV_BF16), (torch.float16, N.PKV_F16)):
         x = bits16.view(tdt).float()
         fin = torch.isfinite(x)
-        a = (x / float(c32)).to(tdt).view(torch.int16)
-        b = (x * torch.tensor(rc, dtype=torch.float32)).to(tdt).view(torch.int16)
-        same = bool((a == b)[fin].all())
-        assert same == expect_equal
+        for D in (64, 128, 256):
+            c32 = np.float32(math.sqrt(float(D)))
+            rc = torch.tensor(float(np.float32(1.0) / c32), dtype=torch.float32)
+            want = {0: (x / float(c32)).to(tdt).view(torch.int16), 1: (x * rc).to(tdt).view(torch.int16)}
+            for mode in (0, 1):
+                m = torch.tensor(N.lib.pkv_debug_scale_multiplier(code, D, mode), dtype=torch.float32)
+                got = (x * m).to(tdt).view(torch.int16)
+                assert bool((got == want[mode])[fin].all()), (tdt, D, mode, float(m))
+            if D == 128:      # why fp16 needs its own constant in "div" mode
+                plain_is_division = bool((want[0] == want[1])[fin].all())
+                assert plain_is_division == (tdt is torch.bfloat16)
+                assert (float(N.lib.pkv_debug_scale_multiplier(code, D, 0)) == float(rc)) == (tdt is torch.bfloat16)
 
 
 def test_headkv_capacity_from_head_scores(P):
