@@ -805,7 +805,7 @@ def config5_extra(P, N, a, dt, dev):
         alg = Hkv * S * D * E + Hq * W * D * E + Hq * (S - W) * E + 4 * klen * D * E
         row = {"update_kv_us": round(call_us, 2), "kernels_us_per_call": kus, "kernels_sum_us": round(ksum, 2),
                "host_sync_remainder_us": round(call_us - ksum, 2), "klen_sum": klen, "max_seqlen_k": int(cl.max_seqlen_k),
-               "list_len": int(getattr(cl, "_list_len", 0)) or None,
+               "list_len": int(cl.ada.prepared.m_use) if cl.ada.prepared is not None else None, "route": cl.ada.route.value, "repeated_calls": cl.ada.repeats,
                "tokens_per_s": round(S / call_us * 1e6, 0),
                "roofline": {"bound": "hbm", "achieved": round(alg / (call_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(alg / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PKV_VERSION 200 /* 0.2.0: pkv_desc starts with struct_size (the struct can grow without breaking hosts built against an
+#define PKV_VERSION 201 /* 0.2.1: + pkv_runtime_reset, pkv_debug_scale_multiplier; pkv_ada_budget_rows validates its host
+                           mirror (8-byte aligned uint64 [H], host_seq >= 0) like pkv_ada_select; no layout change.  0.2.0: pkv_desc starts with struct_size (the struct can grow without breaking hosts built against an
                            older header); pkv_ada_select's budget step is one launch; host mirrors are uint64 [H] of
                            self-validating words; fp32 at D = 256; 0.1.2: short Ada-SnapKV candidate lists */
 /* libpkv.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table (plus nothing). */
@@ -95,6 +96,10 @@ typedef struct pkv_desc {
 PKV_API int pkv_version(void);
 PKV_API const char* pkv_strerror(int status);
 PKV_API int pkv_last_hip_error(void); /* hipError_t of the last PKV_ERR_HIP on this thread */
+/* libpkv remembers, per (kernel, device), how much dynamic LDS it has asked the runtime for (hipFuncSetAttribute is then not
+ * called on every launch).  That grant dies with the context: a host that calls hipDeviceReset() - or unloads and re-creates
+ * the primary context in any other way - calls this afterwards; the attribute is then set again on the next launch. */
+PKV_API int pkv_runtime_reset(void);
 
 /* Bytes of scratch pkv_score_window / pkv_score_h2o / pkv_compress need for `d` (256-B aligned). */
 PKV_API size_t pkv_workspace_bytes(const pkv_desc* d);

@@ -22,7 +22,7 @@ TIE = {"canonical": 0, "aten_rocm": 1}
 KERNEL_NAMES = ["logits", "finalize", "topk", "gather", "h2o_stats", "h2o_colsum", "sort", "budget"]
 
 
-PKV_VERSION = 200            # include/pkv.h PKV_VERSION this binding was written against (checked when the library loads)
+PKV_VERSION = 201            # include/pkv.h PKV_VERSION this binding was written against (checked when the library loads)
 
 
 class PkvDesc(C.Structure):
@@ -66,6 +66,7 @@ def _load():
         "pkv_version": (C.c_int, []),
         "pkv_strerror": (C.c_char_p, [C.c_int]),
         "pkv_last_hip_error": (C.c_int, []),
+        "pkv_runtime_reset": (C.c_int, []),
         "pkv_workspace_bytes": (sz, [dp]),
         "pkv_score_window": (C.c_int, [dp, vp, vp, vp, i64, vp, sz, vp]),
         "pkv_score_h2o": (C.c_int, [dp, vp, vp, vp, i64, vp, sz, vp]),

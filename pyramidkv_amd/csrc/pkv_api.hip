@@ -11,7 +11,7 @@
 #include <mutex>
 #include <vector>
 
-namespace pkv { thread_local KernelEvents* g_kev = nullptr; }
+namespace pkv { thread_local KernelEvents* g_kev = nullptr; unsigned g_dyn_lds_epoch = 1; }
 using namespace pkv;
 
 namespace {
@@ -687,6 +687,8 @@ int pkv_ada_budget_rows(int32_t dtype, int32_t H, int32_t L, const void* scores,
   if (!scores || !head_capacity || !ws) return PKV_ERR_NULL;
   if ((head_lens == nullptr) != (cu_klen == nullptr)) return PKV_ERR_NULL;
   if (H < 1 || H > 256 || L < 1 || base_capacity < 1 || base_capacity > L || scores_stride < L) return PKV_ERR_SHAPE;
+  if (reinterpret_cast<uintptr_t>(host_mirror) & 7) return PKV_ERR_ALIGN;          // 64-bit words since 0.2.0 (was int32 [H+1] before)
+  if (host_mirror && host_seq < 0) return PKV_ERR_SHAPE;
   if (L > (dtype == PKV_F32 ? budget_f32_max_row() : 65536)) return PKV_ERR_UNSUPPORTED;   // a row lives in the registers of one 1024-thread workgroup
   if (ws_bytes < (dtype == PKV_F32 ? 1024 + (size_t)4 * H * 256 * 4 + (size_t)4 * H * 4 : 1024 + (size_t)2 * H * 256 * 4)) return PKV_ERR_WORKSPACE;
   BudgetParams bp;
@@ -833,6 +835,11 @@ int pkv_debug_topk_trace(void* device_u64x8) { return device_u64x8 ? PKV_ERR_UNS
 int pkv_debug_wg_trace(void* device_u64) { return device_u64 ? PKV_ERR_UNSUPPORTED : PKV_OK; }
 int pkv_debug_build(void) { return 0; }
 #endif
+
+int pkv_runtime_reset(void) {
+  ++pkv::g_dyn_lds_epoch;            // every thread's (kernel, device) -> granted-LDS table is dropped on its next launch
+  return PKV_OK;
+}
 
 float pkv_debug_scale_multiplier(int32_t dtype, int32_t D, int32_t scale_mode) { return scale_multiplier(dtype, D, scale_mode); }
 

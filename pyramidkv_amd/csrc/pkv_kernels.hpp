@@ -26,20 +26,25 @@ extern thread_local KernelEvents* g_kev;
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a (kernel, device) pair needs MORE dynamic LDS than it was last
 // granted - not on every launch (one runtime call per update_kv saved for top-k at S >= 16k; bench.py `host_us`).
+// The grant belongs to the loaded code object: a host that calls hipDeviceReset() (or otherwise re-creates the context) must
+// call pkv_runtime_reset() afterwards (include/pkv.h), which empties this table - the attribute is then set again on the next
+// launch.  A table that is full (64 kernels x devices) stops caching: the attribute is then simply set on every launch.
+struct DynLdsRec { const void* fn; int dev; size_t have; };
+struct DynLdsTable { DynLdsRec recs[64]; int n; unsigned epoch; };
+extern unsigned g_dyn_lds_epoch;                       // bumped by pkv_runtime_reset(): every thread's table is stale
 inline hipError_t dyn_lds(const void* fn, size_t bytes) {
-  struct Rec { const void* fn; int dev; size_t have; };
-  static thread_local Rec recs[48];
-  static thread_local int nrec = 0;
+  static thread_local DynLdsTable t = {{}, 0, 0};
+  if (t.epoch != g_dyn_lds_epoch) { t.n = 0; t.epoch = g_dyn_lds_epoch; }
   int dev = 0;
   (void)hipGetDevice(&dev);
-  Rec* hit = nullptr;
-  for (int i = 0; i < nrec; ++i)
-    if (recs[i].fn == fn && recs[i].dev == dev) { hit = &recs[i]; break; }
+  DynLdsRec* hit = nullptr;
+  for (int i = 0; i < t.n; ++i)
+    if (t.recs[i].fn == fn && t.recs[i].dev == dev) { hit = &t.recs[i]; break; }
   if (hit && hit->have >= bytes) return hipSuccess;
   const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   if (hit) hit->have = bytes;
-  else if (nrec < 48) recs[nrec++] = {fn, dev, bytes};
+  else if (t.n < 64) t.recs[t.n++] = {fn, dev, bytes};
   return hipSuccess;
 }
 

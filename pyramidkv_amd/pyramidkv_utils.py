@@ -16,6 +16,7 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
+import enum
 import threading
 import time
 
@@ -450,6 +451,42 @@ class _FlatPolicy:
         return kf, vf
 
 
+class _AdaRoute(enum.Enum):
+    """How an Ada-SnapKV cluster (one per attention layer, :1049) gets from the scores to the head budgets."""
+    LISTS = "lists"   # per-head candidate lists from the top-k kernel: short first, the call repeated with the full length when the
+    #                   budget kernel reports a list that ran out at the threshold (pkv_ada_select)
+    ROWS = "rows"     # budgets from selections / counts over the un-sorted rows (pkv_ada_budget_rows): what a run-out leaves
+    #                   behind when H * base > 4096 (no longer list exists); also fp32 tensors and config.host_poll = 0
+
+
+class _AdaState:
+    """Everything an AdaKVCluster remembers between calls (round 6: one object instead of five ad-hoc attributes).
+
+      route      LISTS until a short list of a LARGE budget (H * base > 4096) runs out, ROWS from then on - never back
+      list_len   0, or the list length a run-out taught this layer (twice the largest share it saw): short lists start there
+      cap_seen   ROWS route: the largest head capacity seen, which sizes the guess the selection is issued with before the sync
+      prepared   the two prepared C calls of the LISTS route for the last operand layouts (_AdaPrepared) or None
+      repeats    how often a call had to be repeated (a list ran out / a guess was too small) - read by tests and bench.py
+
+    A call is: prepared hit -> done, or a run-out -> the general path with ``retry_full``; the general path picks the route,
+    runs it, and leaves `prepared` behind for the next call.  Nothing else is kept on the cluster."""
+    __slots__ = ("route", "list_len", "cap_seen", "prepared", "repeats")
+
+    def __init__(self):
+        self.route = _AdaRoute.LISTS
+        self.list_len = 0
+        self.cap_seen = 0
+        self.prepared = None
+        self.repeats = 0
+
+
+class _AdaPrepared:
+    __slots__ = ("sig", "pa", "mirror", "m_use", "M")
+
+    def __init__(self, sig, pa, mirror, m_use, M):
+        self.sig, self.pa, self.mirror, self.m_use, self.M = sig, pa, mirror, m_use, M
+
+
 class AdaKVCluster(_FlatPolicy):
     """reference pyramidkv_utils.py:622-757 (adapted there from FFY0/AdaKV)."""
 
@@ -465,27 +502,30 @@ class AdaKVCluster(_FlatPolicy):
         self.num_hidden_layers = num_hidden_layers
         self.normalize = normalize
         self.layer_idx = layer_idx
+        self.ada = _AdaState()
         self._init_state()
 
     def _fast_sig(self):
         return (self.window_size, self.pooling, self.kernel_size, self.base_capacity, self.floor_ratio, self.normalize,
-                _cfg.host_poll, _cfg.ada_short_lists, self.__dict__.get("_list_len", 0))
+                _cfg.host_poll, _cfg.ada_short_lists, self.ada.list_len)
 
     def update_kv(self, key_states, query_states, value_states):
         # fast path (round 5): the two C calls prepared by an earlier update_kv of this cluster with the same layouts, list length
         # and knobs (ops.PreparedAda) - between the capacities arriving on the host and the first kernel of the NEXT call lies
         # nothing but this check, one allocation and one foreign call (the host sync of the policy, :718, makes every
         # microsecond of host work here a microsecond of idle GPU)
-        fast = self.__dict__.get("_fast")
-        if fast is not None and fast[0] == self._fast_sig() and fast[1].hit(query_states, key_states, value_states):
-            pa, mirror, m_use, M = fast[1], fast[2], fast[3], fast[4]
+        st = self.ada
+        retry_full = False               # this call only: the prepared call below saw a list run out
+        fast = st.prepared
+        if fast is not None and fast.sig == self._fast_sig() and fast.pa.hit(query_states, key_states, value_states):
+            pa, mirror = fast.pa, fast.mirror
             out = pa.run(query_states, key_states, value_states, mirror.ptr, mirror.next_seq())
             if out is not None:
                 head_lens, cu, cuh, kf, vf = out
                 num_heads, w = pa.H, self.window_size
                 self._init_metadata(num_heads, head_lens, cu, 0, 0, pa.device, cu_headlens=cuh)    # everything but the two host ints
                 words = mirror.wait_words(pa.device)
-                if not (mirror.exhausted and m_use < M):
+                if not (mirror.exhausted and fast.m_use < fast.M):
                     # the words share their upper halves (sequence number, ran-out bit): sum and maximum of the capacities come
                     # from sum and maximum of the words - between the flag and the return every microsecond is idle GPU
                     flags = words[0] & ~0x7fffffff
@@ -494,8 +534,9 @@ class AdaKVCluster(_FlatPolicy):
                     self.max_seqlen_k = (max(words) & 0x7fffffff) + w                    # :686
                     self._cap_words = words
                     return kf[:klen_sum], vf[:klen_sum]
-                self._fast = None                                    # a list ran out: the general path repeats with the full length
-                self._force_full = True
+                st.prepared = None                                   # a list ran out: the general path repeats with the full length
+                st.repeats += 1
+                retry_full = True
         bsz, num_heads, q_len, head_dim = query_states.shape
         L = q_len - self.window_size
         if self.base_capacity > L:                                                   # :700
@@ -513,10 +554,10 @@ class AdaKVCluster(_FlatPolicy):
         # path below for good (there is no longer list to repeat with).
         full_ok = M <= _ADA_TOPM_MAX
         short_big = (not full_ok and _cfg.host_poll and _cfg.ada_short_lists > 0 and 2 * self.base_capacity <= _ADA_TOPM_MAX
-                     and not self.__dict__.get("_lists_off"))
-        ran_out = self.__dict__.pop("_force_full", False)                # the fast path above saw a list run out
+                     and st.route is _AdaRoute.LISTS)
+        ran_out = retry_full
         if ran_out and not full_ok:
-            self._lists_off, short_big = True, False
+            st.route, short_big = _AdaRoute.ROWS, False
         if (full_ok or short_big) and key_states.dtype != torch.float32:      # fp32 tensors take the un-sorted-rows path below
             if self.pooling not in ('avgpool', 'maxpool'):
                 raise ValueError('Pooling method not supported')
@@ -533,7 +574,7 @@ class AdaKVCluster(_FlatPolicy):
             def short_len():
                 if not full_ok:          # large budgets: 2.5 x base, what the list path can hold at most
                     return min(_ADA_TOPM_MAX, max(2 * self.base_capacity, (5 * self.base_capacity) // 2, 512))
-                return min(M, max(getattr(self, "_list_len", 0), _cfg.ada_short_lists * self.base_capacity, 512))
+                return min(M, max(st.list_len, _cfg.ada_short_lists * self.base_capacity, 512))
             m_use = M
             if mirror is not None and _cfg.ada_short_lists > 0:
                 m_use = short_len()
@@ -550,15 +591,16 @@ class AdaKVCluster(_FlatPolicy):
                                                rows_bound=bound, mirror=mirror)
                 if m_use == M or not mirror.exhausted:
                     if ran_out:      # remembered from now on: this layer's heads want longer lists than the default
-                        self._list_len = max(getattr(self, "_list_len", 0), min(M, 2 * max(self.head_capacity_last)))
+                        st.list_len = max(st.list_len, min(M, 2 * max(self.head_capacity_last)))
                     if mirror is not None:                           # the next call with these layouts takes the fast path above
                         m_next = short_len() if _cfg.ada_short_lists > 0 else M
                         pa = ops.prepare_ada(query_states, key_states, value_states, self.window_size, self.pooling, self.kernel_size,
                                              m_next, self.base_capacity, self.floor_ratio, bool(self.normalize), _cfg.scale_mode, gq, bound)
-                        self._fast = (self._fast_sig(), pa, mirror, m_next, M) if pa is not None else None
+                        st.prepared = _AdaPrepared(self._fast_sig(), pa, mirror, m_next, M) if pa is not None else None
                     return out
+                st.repeats += 1
                 if not full_ok:                                      # large budget: no longer list exists - the un-sorted rows from now on
-                    self._lists_off = True
+                    st.route = _AdaRoute.ROWS
                     break
                 ran_out, m_use = True, M
         # H*base > 4096 (budget 2048: M is the whole row, a top-M list would be a full sort).  What :706-719 consume of the
@@ -582,7 +624,7 @@ class AdaKVCluster(_FlatPolicy):
             # and outputs sized by the bound sum_h cap_h <= H*base + H/2; the read-back then only narrows the views.  Round 4
             # waited for the capacities first: the GPU idled for the host's round trip in the middle of every call (~10 us of
             # ~120 at budget 2048).  A capacity beyond the guess (checked after the wait) repeats selection + gather the old way.
-            guess = min(L, max(2 * self.base_capacity, 2 * getattr(self, "_cap_seen", 0)))
+            guess = min(L, max(2 * self.base_capacity, 2 * st.cap_seen))
             if mirror is not None and key_states.dtype != torch.float32 and ops.topk_fits(num_heads, L, guess):
                 g = num_heads // key_states.shape[1]
                 bound = num_heads * self.base_capacity + num_heads + num_heads * self.window_size
@@ -594,7 +636,8 @@ class AdaKVCluster(_FlatPolicy):
                     self._init_metadata(num_heads, head_lens, cu, klen_sum, max(caps) + self.window_size, key_states.device, cu_headlens=cuh)
                     self.head_capacity_last = caps
                     return kf[:klen_sum], vf[:klen_sum]
-                self._cap_seen = max(caps)                                               # the guess was too small: the exact path below
+                st.cap_seen = max(caps)                                                  # the guess was too small: the exact path below
+                st.repeats += 1
             else:
                 caps = mirror.wait(key_states.device) if mirror is not None else _read_back(cap)   # the one host sync (:718)
             kmax = max(1, max(caps))

@@ -484,7 +484,7 @@ def test_adakv_short_list_retry_logic_on_the_host(monkeypatch):
     monkeypatch.setattr(cfg, "ada_short_lists", 2)
     q = torch.zeros(1, H, S, 16, dtype=torch.bfloat16)
     assert cl.update_kv(q, q, q) == ("K", "V")
-    assert calls == [600, 1200] and cl._list_len == 1200       # ran out at 600 -> full length; remembers min(M, 2 x 900)
+    assert calls == [600, 1200] and cl.ada.list_len == 1200       # ran out at 600 -> full length; remembers min(M, 2 x 900)
     calls.clear()
     assert cl.update_kv(q, q, q) == ("K", "V") and calls == [1200]
     # lists that never run out leave nothing remembered: the next call starts short again (round 5: a remembered length above
@@ -495,7 +495,7 @@ def test_adakv_short_list_retry_logic_on_the_host(monkeypatch):
     calls.clear()
     cl3.update_kv(q, q, q)
     cl3.update_kv(q, q, q)
-    assert calls == [600, 600] and not hasattr(cl3, "_list_len")
+    assert calls == [600, 600] and cl3.ada.list_len == 0 and cl3.ada.repeats == 0
     run_out_below[0] = 1000
     # the floor of 512 entries: short lists of base budgets below 128 tokens still fill the small-k path
     cl4 = U.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=8 + 100, floor=0.2, normalize=True)

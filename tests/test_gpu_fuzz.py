@@ -3,7 +3,10 @@
 Exact stages (a failure is a bug): indices == canonical top-k of the kernel's own scores, K/V == the exact gather, Ada-SnapKV
 budgets == the oracle's arithmetic on the kernel's scores, LOOK-M merge == the oracle on the selected indices.
 Floating-point stage: tests/score_bar.py - every score within 1 ulp of the oracle or reproduced by the oracle with one
-product q.k of that position rounded to its neighbour; no tolerance is loosened for these seeds.
+product q.k of that position rounded to its neighbour (asserted as in every other test).  The one bar that differs from the
+full-size tests is the FRACTION of scores allowed to sit one ulp off: 2e-2 here (score_bar's defaults are 2e-3 for window scores
+and 1e-3 for H2O) - the fuzz tensors are small (down to a few hundred scores per case), where three or four one-ulp elements
+are already a per-cent; the largest fraction seen is reported per seed (`max_mismatch_frac`).
 A fixed number of cases per seed (not a time budget): the set of cases does not depend on the speed of the box."""
 import json
 import os

@@ -767,19 +767,19 @@ def test_adakv_large_budget_without_the_sort(P):
     caps = caps[0].tolist()
     kr, vr, _ = O._flat_gather(k, v, [sidx[0, h, :caps[h]] for h in range(H)], w)
     # round 5: large budgets first try SHORT lists of 2 x base entries per head through the list path (exact unless a list runs
-    # out); `_lists_off` is what a run-out leaves behind: the un-sorted-rows path of round 3.  Both give the oracle's bytes,
+    # out); route ROWS is what a run-out leaves behind: the un-sorted-rows path of round 3.  Both give the oracle's bytes,
     # also on the second call of the same cluster (prepared path / selection issued before the host sync).
     for lists_off in (False, True):
         cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2,
                             normalize=True, layer_idx=0, num_hidden_layers=32)
         if lists_off:
-            cl._lists_off = True
+            cl.ada.route = P.pyramidkv_utils._AdaRoute.ROWS
         for _ in range(2):
             kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
             assert cl.head_lens.cpu().tolist() == [c + w for c in caps], lists_off
             assert int(cl.klen_sum) == sum(caps) + H * w == kf.shape[0] and cl.max_seqlen_k == max(caps) + w
             assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr), lists_off
-        assert bool(cl.__dict__.get("_lists_off")) == lists_off
+        assert (cl.ada.route is P.pyramidkv_utils._AdaRoute.ROWS) == lists_off
     # one head that takes more than twice its base budget: the short lists run out, the call falls back by itself
     m_short = min(4096, (5 * (cap - w)) // 2)
     for span, gain in ((4000, 0.9), (6000, 1.5), (7000, 2.5), (8000, 4.0)):
@@ -797,7 +797,9 @@ def test_adakv_large_budget_without_the_sort(P):
         kr2_, vr2_, _ = O._flat_gather(k2, v, [sidx2[0, h, :caps2[h]] for h in range(H)], w)
         assert cl.head_lens.cpu().tolist() == [c + w for c in caps2]
         assert torch.equal(kf2.cpu(), kr2_) and torch.equal(vf2.cpu(), vr2_)
-    assert cl._lists_off
+    # two re-dos in the first call (the short list ran out; on the un-sorted-rows route the first guess of the largest capacity was too
+    # small), none in the second
+    assert cl.ada.route is P.pyramidkv_utils._AdaRoute.ROWS and cl.ada.repeats == 2
     cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2,
                         normalize=True, layer_idx=0, num_hidden_layers=32)
     kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
@@ -858,8 +860,8 @@ def test_adakv_short_candidate_lists_are_exact_or_repeated(P, dt):
                 outs[factor] = (kf.cpu(), vf.cpu(), cl.head_lens.cpu().tolist(), cl.cu_klen.cpu().tolist(), cl.klen_sum, cl.max_seqlen_k)
                 if factor:
                     M = min(S - w, H * (cap - w))
-                    if hasattr(cl, "_list_len"):             # set when a list ran out: the length this layer is served with from now on
-                        assert cl._list_len >= min(M, 2 * max(cl.head_capacity_last))
+                    if cl.ada.list_len:             # set when a list ran out: the length this layer is served with from now on
+                        assert cl.ada.list_len >= min(M, 2 * max(cl.head_capacity_last)) and cl.ada.repeats >= 1
                     else:
                         assert max(cl.head_capacity_last) < max(factor * (cap - w), 512)
                     kf2, vf2 = cl.update_kv(kd, qd, vd)                  # second call of the same cluster: the remembered length
@@ -1475,3 +1477,71 @@ def test_config_knobs_gqa_dedup_and_scale_mode(P):
         assert torch.equal(a, b)
     for a, b in zip(ref, rcp):
         assert torch.equal(a, b)
+
+
+# ----------------------------------------------------------------------------------------- Ada-SnapKV: ONE cluster, many prompts
+def _ada_expected(P, q, k, v, w, cap, floor=0.2, normalize=True):
+    """(head capacities, flat K, flat V) the exact stages must produce from the kernels' OWN scores (pyramidkv_utils.py:706-757)."""
+    sg = P.ops.score_window(q.to(DEV), k.to(DEV), w, "maxpool", 7, "mean").cpu()[0]
+    sidx, caps = O.adakv_head_capacity(sg[None], cap - w, floor, normalize)
+    caps = caps[0].tolist()
+    kr, vr, _ = O._flat_gather(k, v, [sidx[0, h, :caps[h]] for h in range(q.shape[1])], w)
+    return caps, kr, vr
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_adakv_one_cluster_random_prompt_sequences(P, big):
+    """The host side of Ada-SnapKV is a small state machine (pyramidkv_utils._AdaState: route LISTS / ROWS, remembered list
+    length, prepared calls).  Round 5 tested its routes one at a time; here ONE cluster - the reference builds one per layer
+    and keeps it for the whole session (:1049) - is driven through a seeded random sequence of prompts: balanced ones, prompts
+    where one head wants several base budgets (a short list runs out: the call is repeated, the state changes), another prompt
+    length in between (the prepared call does not apply).  After EVERY call: head budgets, metadata and flat K/V are exactly
+    what the reference's stages give on the kernels' own scores; the end-to-end oracle comparison is recorded.  `big`: H x base
+    > 4096 (budget 1032 at H = 8), where a run-out moves the cluster to the un-sorted-rows route for good."""
+    rng = np.random.default_rng(20260930 + int(big))
+    if big:
+        H, S0, w, cap = 8, 8192, 8, 1032
+    else:
+        H, S0, w, cap = 16, 6000, 8, 72
+    base = cap - w
+    cl = P.AdaKVCluster(window_size=w, kernel_size=7, pooling="maxpool", max_capacity_prompt=cap, floor=0.2, normalize=True,
+                        layer_idx=0, num_hidden_layers=32)
+    route = P.pyramidkv_utils._AdaRoute
+    kinds = ["balanced", "balanced", "skewed", "balanced", "other_length", "skewed", "balanced", "mild", "balanced", "skewed"]
+    order = [0, 1] + list(rng.permutation(np.arange(2, len(kinds))))          # starts balanced (the prepared call exists), then random
+    e2e_same, calls, repeats_seen = 0, 0, []
+    for step, ki in enumerate(order):
+        kind = kinds[ki]
+        S = S0 - 1000 if kind == "other_length" else S0
+        q, k, v = make_qkv(1, H, S, 128, "bf16", "gauss", 9100 + 17 * step + int(big))
+        if kind == "skewed":          # one head looks at thousands of keys as hard as the others look at their best few
+            h = int(rng.integers(0, H))
+            k[0, h, 100:S - 500] += (4.0 if big else 0.9) * q[0, h, -1]
+        elif kind == "mild":
+            h = int(rng.integers(0, H))
+            k[0, h, 100:400] += 0.5 * q[0, h, -1]
+        caps, kr, vr = _ada_expected(P, q, k, v, w, cap)
+        before = cl.ada.repeats
+        kf, vf = cl.update_kv(k.to(DEV), q.to(DEV), v.to(DEV))
+        calls += 1
+        repeats_seen.append(cl.ada.repeats - before)
+        assert cl.head_capacity_last == caps, (step, kind, cl.ada.route)
+        assert cl.head_lens.cpu().tolist() == [c + w for c in caps]
+        assert cl.cu_klen.cpu().tolist() == [0] + np.cumsum([c + w for c in caps]).tolist()
+        assert int(cl.klen_sum) == sum(caps) + H * w == kf.shape[0] and int(cl.max_seqlen_k) == max(caps) + w
+        assert torch.equal(kf.cpu(), kr) and torch.equal(vf.cpu(), vr), (step, kind)
+        kr2, vr2, meta = O.adakv_update_kv(k, q, v, w, cap, 7, "maxpool", 0.2, True)
+        e2e_same += int(meta.head_lens.tolist() == cl.head_lens.cpu().tolist() and torch.equal(kf.cpu(), kr2) and torch.equal(vf.cpu(), vr2))
+    _report(f"adakv_sequences/{'big' if big else 'small'}", dict(calls=calls, repeats=cl.ada.repeats, repeats_per_call=repeats_seen,
+                                                                  end_to_end_oracle_identical=e2e_same, route=cl.ada.route.value,
+                                                                  list_len=cl.ada.list_len))
+    # a call is re-done at most once per cause: a list that ran out, and (large budgets, right after it) a first guess of the
+    # largest capacity that was too small
+    assert max(repeats_seen) <= (2 if big else 1)
+    assert cl.ada.repeats >= 1                                      # the skewed prompts really ran a list out
+    if big:
+        assert cl.ada.route is route.ROWS                           # and never went back
+    else:
+        assert cl.ada.route is route.LISTS and cl.ada.list_len >= 2 * base
+        assert sum(repeats_seen) <= 2                               # the remembered length serves the later skewed prompts
+    assert e2e_same >= calls - 1, (e2e_same, calls)
