@@ -622,7 +622,7 @@ def test_prepared_calls_follow_layout_and_knob_changes(P):
     ac = P.AdaKVCluster(**akw)
     r1 = ac.update_kv(ka, qa, va)
     r2 = ac.update_kv(ka, qa, va)
-    assert ac.__dict__.get("_fast") is not None and torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+    assert ac.ada.prepared is not None and torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
     ac.floor_ratio, ac.floor_capacity = 0.5, int(ac.base_capacity * 0.5)
     r3 = ac.update_kv(ka, qa, va)
     f3 = P.AdaKVCluster(**dict(akw, floor=0.5))

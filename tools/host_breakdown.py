@@ -76,6 +76,6 @@ for _ in range(n):
 torch.cuda.synchronize()
 tot = (time.perf_counter() - t0) / n * 1e6
 res["adakv_S32768_budget128"] = {"update_kv_us": round(tot, 2), "of_which_waiting_for_the_capacities_us": round(sum(waits) / n * 1e6, 2),
-                                 "host_work_us": round(tot - sum(waits) / n * 1e6, 2), "prepared": cl.__dict__.get("_fast") is not None,
+                                 "host_work_us": round(tot - sum(waits) / n * 1e6, 2), "prepared": cl.ada.prepared is not None,
                                  "list_len": cl.ada.prepared.m_use if cl.ada.prepared is not None else None}
 print(json.dumps(res, indent=1))
