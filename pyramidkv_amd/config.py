@@ -20,6 +20,10 @@ host_poll = os.environ.get("PKV_HOST_POLL", "1") == "1"
 # 0 = always the full length.  Needs host_poll.
 ada_short_lists = int(os.environ.get("PKV_ADA_SHORT_LISTS", "4"))
 
+# Ada-SnapKV prepared calls: host work that does not need the capacities (the outputs narrowed to the last call's total, the
+# next call's metadata buffer) is done while the kernels run, when the capacities have not arrived yet (round 6).  0: off (A/B runs).
+ada_prewait = os.environ.get("PKV_ADA_PREWAIT", "1") == "1"
+
 # Order of equal scores in the selected rows: "canonical" = (value descending, index ascending), what PyTorch-ROCm's topk gives
 # for k > 32; "aten_rocm" additionally reproduces, for k <= 32, the order its unstable small-slice sort leaves them in - the
 # cache rows of PyramidKV's upper layers (k = 17..32) then match a reference run on the same GPU row for row.

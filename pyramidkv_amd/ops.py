@@ -368,7 +368,7 @@ class PreparedAda:
     capacities) for fixed shapes and list length M.  ``run`` returns (head_lens, cu_klen, cu_headlens, K_flat, V_flat) with the
     flat outputs sized by ``rows_bound``; the caller narrows them once the capacities are on the host."""
     __slots__ = ("qs", "ks", "vs", "qst", "kst", "vst", "dtype", "device", "dev_index", "H", "M", "D", "dsel", "dsel_ref", "nb",
-                 "dgat", "dgat_ref", "rows_bound", "sizes", "base", "floor", "normalize", "knobs", "f_sel", "f_gat")
+                 "dgat", "dgat_ref", "rows_bound", "sizes", "base", "floor", "normalize", "knobs", "f_sel", "f_gat", "_spare")
 
     hit = PreparedCompress.hit
 
@@ -383,7 +383,11 @@ class PreparedAda:
         ws = _WS.get((self.dev_index, st))
         if ws is None or ws.numel() < self.nb:
             ws = _workspace_and_stream(self.nb, self.device)[0]
-        buf = torch.empty(4 * H + 1 + H * M, dtype=torch.int32, device=self.device)     # cap | head_lens | cu_klen | cu_headlens | lists
+        buf = self._spare                                                               # cap | head_lens | cu_klen | cu_headlens | lists
+        if buf is None:
+            buf = torch.empty(4 * H + 1 + H * M, dtype=torch.int32, device=self.device)
+        else:
+            self._spare = None       # a fresh tensor per call: the metadata views of this call's result own it
         p0 = buf.data_ptr()
         p_hl, p_cu, p_cuh, p_top = p0 + 4 * H, p0 + 8 * H, p0 + 4 * (3 * H + 1), p0 + 4 * (4 * H + 1)
         rc = self.f_sel(self.dsel_ref, qp, kp, self.base, self.floor, self.normalize, given_ptr, p_top, p0, p_hl, p_cu, p_cuh,
@@ -398,6 +402,13 @@ class PreparedAda:
             N.check(rc, "pkv_gather_flat")
         _, head_lens, cu, cuh, _ = buf.split(self.sizes)          # views for the metadata attributes: after both calls are issued
         return head_lens, cu, cuh, kf, vf
+
+    def spare(self):
+        """Allocate the NEXT run's metadata buffer now (the caller is about to wait for this run's kernels anyway): the
+        allocation then no longer sits between that call's entry and its first launch.  66 KB per cluster at H = 32, M = 512;
+        given back to the allocator when the cluster is."""
+        if self._spare is None:
+            self._spare = torch.empty(4 * self.H + 1 + self.H * self.M, dtype=torch.int32, device=self.device)
 
 
 def prepare_ada(q, k, v, window: int, pooling, kernel_size: int, M: int, base_capacity: int, floor_ratio: float, normalize: bool,
@@ -424,6 +435,7 @@ def prepare_ada(q, k, v, window: int, pooling, kernel_size: int, M: int, base_ca
     pa.base, pa.floor, pa.normalize = int(base_capacity), float(floor_ratio), 1 if normalize else 0
     pa.knobs = (_cfg.scale_mode, _cfg.tie_order, _cfg.gqa_dedup)
     pa.f_sel, pa.f_gat = N.lib.pkv_ada_select, N.lib.pkv_gather_flat
+    pa._spare = None
     return pa
 
 

@@ -330,6 +330,10 @@ class _HostMirror:
         self.seq = self.seq % 0x3fffffff + 1
         return self.seq
 
+    def arrived(self):
+        """One look at the last word: has the budget kernel of the current sequence number written the capacities?"""
+        return (int(self.np[self.H - 1]) >> 32) == self.seq
+
     def wait_words(self, device):
         """-> the H raw words once every one of them carries the current sequence number (word h = seq << 32 | ran_out << 31 |
         cap_h, so "all carry seq" is one min and one max over the list); ``self.exhausted`` = bit 31."""
@@ -340,7 +344,8 @@ class _HostMirror:
         while True:
             if lo <= int(a[last]) < hi:          # the heads' stores leave together: look at one word, then check all of them
                 vals = a.tolist()                # copied out before the next call of this instance can reuse the buffer
-                if lo <= min(vals) and max(vals) < hi:
+                mx = max(vals)
+                if lo <= min(vals) and mx < hi:
                     break
             spins += 1
             if spins & 63 == 0:
@@ -348,10 +353,12 @@ class _HostMirror:
                 if time.perf_counter() > t_end:  # a lost signal must not hang the host: fall back
                     torch.cuda.current_stream(device).synchronize()
                     vals = a.tolist()
-                    if not (lo <= min(vals) and max(vals) < hi):
+                    mx = max(vals)
+                    if not (lo <= min(vals) and mx < hi):
                         raise RuntimeError("pyramidkv_amd: the budget kernel did not report its head capacities")
                     break
         self.exhausted = bool(vals[0] & 0x80000000)
+        self.max_word = mx               # the largest word (same upper half everywhere: the largest capacity)
         return vals
 
     def wait(self, device):
@@ -467,10 +474,12 @@ class _AdaState:
       cap_seen   ROWS route: the largest head capacity seen, which sizes the guess the selection is issued with before the sync
       prepared   the two prepared C calls of the LISTS route for the last operand layouts (_AdaPrepared) or None
       repeats    how often a call had to be repeated (a list ran out / a guess was too small) - read by tests and bench.py
+      klen_last  `klen_sum` of the last prepared call: the flat outputs are narrowed to it BEFORE the host sync (the totals of one
+                 layer differ between prompts only by the roundings of :719) and the views are kept when the capacities agree
 
     A call is: prepared hit -> done, or a run-out -> the general path with ``retry_full``; the general path picks the route,
     runs it, and leaves `prepared` behind for the next call.  Nothing else is kept on the cluster."""
-    __slots__ = ("route", "list_len", "cap_seen", "prepared", "repeats")
+    __slots__ = ("route", "list_len", "cap_seen", "prepared", "repeats", "klen_last")
 
     def __init__(self):
         self.route = _AdaRoute.LISTS
@@ -478,6 +487,7 @@ class _AdaState:
         self.cap_seen = 0
         self.prepared = None
         self.repeats = 0
+        self.klen_last = 0
 
 
 class _AdaPrepared:
@@ -524,15 +534,28 @@ class AdaKVCluster(_FlatPolicy):
                 head_lens, cu, cuh, kf, vf = out
                 num_heads, w = pa.H, self.window_size
                 self._init_metadata(num_heads, head_lens, cu, 0, 0, pa.device, cu_headlens=cuh)    # everything but the two host ints
+                # Round 6: host work that does not need the capacities happens HERE, while the kernels run - after the wait every
+                # microsecond of it is idle GPU.  (a) The outputs narrowed to the last call's total (two view ops, ~2.4 us).
+                # (b) The NEXT call's metadata buffer (its torch.empty sits in front of that call's first launch, ~1.6 us).
+                # Only when the capacities have not arrived yet (a short prompt's kernels can be done before the host has issued
+                # them all: then this work would sit between the arrival and the return).
+                guess = 0
+                if _cfg.ada_prewait and not mirror.arrived():
+                    guess = st.klen_last
+                    kg, vg = (kf[:guess], vf[:guess]) if guess else (None, None)
+                    pa.spare()
                 words = mirror.wait_words(pa.device)
                 if not (mirror.exhausted and fast.m_use < fast.M):
                     # the words share their upper halves (sequence number, ran-out bit): sum and maximum of the capacities come
-                    # from sum and maximum of the words - between the flag and the return every microsecond is idle GPU
+                    # from sum and maximum of the words (wait_words leaves the maximum behind: it validated the list with it)
                     flags = words[0] & ~0x7fffffff
                     klen_sum = sum(words) - num_heads * flags + num_heads * w
                     self.klen_sum = klen_sum                                             # :685
-                    self.max_seqlen_k = (max(words) & 0x7fffffff) + w                    # :686
+                    self.max_seqlen_k = (mirror.max_word & 0x7fffffff) + w               # :686
                     self._cap_words = words
+                    if klen_sum == guess:
+                        return kg, vg
+                    st.klen_last = klen_sum
                     return kf[:klen_sum], vf[:klen_sum]
                 st.prepared = None                                   # a list ran out: the general path repeats with the full length
                 st.repeats += 1

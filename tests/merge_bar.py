@@ -1,0 +1,97 @@
+"""The bar for the LOOK-M merge (reference pyramidkv_utils.py:119-170) - the true statement, like score_bar.py for the scores.
+
+Every stage of the merge is exact integer / rounding arithmetic EXCEPT one: the cosine similarity is a 128-term dot product
+accumulated in fp32 and rounded to the model dtype (:150).  Two correct fp32 accumulations (ATen's CPU GEMM, the MFMA) may differ
+in the last fp32 place, and when the exact value lies within that distance of a model-dtype rounding MIDPOINT the rounded
+similarity differs by one unit - which changes `similarity.max(dim=-1)` (:151) only when that similarity is the row's maximum or
+ties it.  `tools/parity_fuzz.py` seed 60606 case 507 is such a case (one dropped row of 13 904: exact dot 0.26660159754, midpoint
+0.2666015625; the kernel's rounding is the correctly rounded one; `profiles/r06/merge_case_diag.json`).
+
+`check_merge` therefore asserts: K and V equal the oracle's bit for bit - OR the kernel's own drop list equals the oracle's,
+every pivot that differs is reachable by moving dot products by at most one fp32 unit (each similarity may take the rounding of
+exact*(1 -/+ 2^-22); the kernel's pivot must be a possible FIRST maximum), such rows are at most max(2, 1e-4 x dropped rows), and the
+oracle's arithmetic run with the KERNEL's pivots reproduces the kernel's K and V bit for bit (everything behind the argmax is
+exact).  The kernel's drop list and pivots are read from the workspace of the call (layout of pkv_api.hip `merge_ws`)."""
+import numpy as np
+import torch
+
+from oracle import pkv_oracle as O
+
+
+def _al(x, a=256):
+    return (x + a - 1) // a * a
+
+
+def kernel_pivots(ops, device, B, H, S):
+    """(drop list, pivots [B*H, ndrop]) of the LAST pkv_merge_compact on the current stream of `device`."""
+    torch.cuda.synchronize()
+    ws = ops.workspace(1, device).cpu().numpy()
+    o = _al(S)                      # mask
+    o = _al(o + B * H * 4)          # kept_bad
+    off_n = o
+    o = _al(o + 4)
+    off_drop = o
+    o = _al(o + S * 4)
+    off_pivot = o
+    ndrop = int(ws[off_n:off_n + 4].view(np.int32)[0])
+    drop = ws[off_drop:off_drop + 4 * ndrop].view(np.int32).astype(np.int64)
+    piv = ws[off_pivot:off_pivot + 4 * B * H * S].view(np.int32).reshape(B * H, S)[:, :ndrop].astype(np.int64)
+    return drop, piv
+
+
+def merge_with_pivots(Kh, Vh, sel, drop, pivot, w):
+    """merge_kv_explicit's arithmetic for ONE head with given pivots (fp32 accumulation in ascending dropped position)."""
+    S, tdt = Kh.shape[0], Kh.dtype
+    rnd = lambda x: x.to(tdt).float()      # noqa: E731
+    Kf, Vf = Kh.float(), Vh.float()
+    tgt_k = torch.cat([Kf[S - w:], Kf[sel]], 0)
+    tgt_v = torch.cat([Vf[sel], Vf[S - w:]], 0)
+    acc_k, acc_v, cnt = tgt_k.clone(), tgt_v.clone(), torch.ones(tgt_k.shape[0])
+    for i, p in enumerate(drop):
+        j = int(pivot[i])
+        acc_k[j] = acc_k[j] + rnd(rnd(Kf[p] + tgt_k[j]) / 2)
+        acc_v[j] = acc_v[j] + rnd(rnd(Vf[p] + tgt_v[j]) / 2)
+        cnt[j] += 1
+    return (rnd(acc_k) / rnd(cnt)[:, None]).to(tdt), (rnd(acc_v) / rnd(cnt)[:, None]).to(tdt)
+
+
+def check_merge(ops, ke, ve, idx, w, km, vm, what=""):
+    """ke / ve: expanded CPU tensors [B,H,S,D]; idx: CPU int64 [B,H,k]; km / vm: the kernel's outputs (device or CPU).
+    -> number of pivots that differed (0 = bit-identical to the oracle)."""
+    km, vm = km.cpu(), vm.cpu()
+    kmr, vmr = O.merge_kv(ke, ve, idx, w, "pivot")
+    if torch.equal(km, kmr) and torch.equal(vm, vmr):
+        return 0
+    B, H, S, D = ke.shape
+    drop_k, piv_k = kernel_pivots(ops, torch.device("cuda", torch.cuda.current_device()), B, H, S)
+    union = set(idx.flatten().tolist())
+    drop = [p for p in range(S) if p not in union]
+    assert drop == drop_k.tolist(), (what, "drop list")
+    tdt = ke.dtype
+    rnd = lambda x: x.to(tdt).float()      # noqa: E731
+    moved = 0
+    for b in range(B):
+        for h in range(H):
+            if torch.equal(km[b, h], kmr[b, h]) and torch.equal(vm[b, h], vmr[b, h]):
+                continue
+            Kf = ke[b, h].float()
+            sel = idx[b, h]
+            tgt = torch.cat([Kf[S - w:], Kf[sel]], 0)
+            unit = lambda X: rnd(X / rnd(torch.sqrt((X * X).sum(-1)))[:, None])      # noqa: E731
+            ud, ut = unit(Kf[drop]), unit(tgt)
+            sim = rnd(ud @ ut.T)
+            piv_o = (sim == sim.max(-1, keepdim=True).values).float().argmax(-1).numpy()
+            pk = piv_k[b * H + h]
+            for i in np.nonzero(piv_o != pk)[0]:
+                ex = (ud[i].double()[None, :] * ut.double()).sum(-1)                  # exact dot products of this dropped row
+                eps = ex.abs() * 2.0 ** -22
+                lo, hi = rnd((ex - eps).float()), rnd((ex + eps).float())
+                jk = int(pk[i])
+                # the kernel's pivot can be the FIRST maximum: nothing before it must exceed or reach it, nothing behind it exceed it
+                ok = bool((lo[:jk] < hi[jk]).all()) and bool((lo[jk + 1:] <= hi[jk]).all())
+                assert ok, (what, "pivot not explained by one fp32 unit of a dot product", b, h, int(drop[i]), int(piv_o[i]), jk)
+                moved += 1
+            k2, v2 = merge_with_pivots(ke[b, h], ve[b, h], sel, drop, pk, w)
+            assert torch.equal(km[b, h], k2) and torch.equal(vm[b, h], v2), (what, "merge arithmetic behind the kernel's own pivots", b, h)
+    assert 0 < moved <= max(2, int(1e-4 * len(drop) * B * H)), (what, "pivots moved", moved, len(drop) * B * H)
+    return moved
