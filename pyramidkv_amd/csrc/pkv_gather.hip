@@ -42,27 +42,23 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
   const int h = bh - b * p.H;
   const int hk = h / p.G;
   const int L = p.S - p.w;
-  const int nsel = p.head_k ? p.head_k[bh] : p.nsel;
-  const int nrows = nsel + p.w;
   const int r_blk = blk * ROWS;
-  if (r_blk >= nrows) return;
-  const unsigned long long t_start = PKV_WGTRACE(p) ? wall_clock64() : 0ull;
-  const int64_t out_row0 = p.cu_rows ? (int64_t)p.cu_rows[bh] : (int64_t)bh * nrows;
-
-  const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h + chunk * 8;
-  const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.vptr) + (int64_t)b * p.vs_b + (int64_t)hk * p.vs_h + chunk * 8;
   const int32_t* ib = p.idx ? p.idx + (int64_t)bh * p.idx_stride : nullptr;
 
   // All loads are unconditional (invalid slots read row 0 and are simply not stored) so that the RPT
   // index loads and then the 2*RPT 16-B row loads are issued back to back: two dependent memory round
   // trips per workgroup instead of one per row.
+  // Round 6: the index loads go out FIRST, before the head's own row count and output offset (flat var-len layout: head_k,
+  // cu_rows) are even asked for - their addresses do not depend on those, so a flat gather pays two dependent round trips
+  // like the dense one, not three.
   int src[RPT];
   bool ok[RPT];
   int gi[RPT];
   if (ib) {                                     // uniform branch; the loads inside are unconditional
     // never past the row of the index list: a capacity beyond the list length (a caller that sized the list by a guess and
-    // checks the capacities afterwards) re-reads the row's last entry instead of running into the next row
-    const int last = min(nsel > 0 ? nsel - 1 : 0, (int)p.idx_stride - 1);
+    // checks the capacities afterwards) re-reads the row's last entry instead of running into the next row; entries at or
+    // beyond the head's own count are loaded and never used
+    const int last = (int)p.idx_stride - 1;
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
       const int r = r_blk + j * SLOTS + slot;
@@ -72,6 +68,14 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
 #pragma unroll
     for (int j = 0; j < RPT; ++j) gi[j] = r_blk + j * SLOTS + slot;
   }
+  const int nsel = p.head_k ? p.head_k[bh] : p.nsel;
+  const int nrows = nsel + p.w;
+  if (r_blk >= nrows) return;
+  const unsigned long long t_start = PKV_WGTRACE(p) ? wall_clock64() : 0ull;
+  const int64_t out_row0 = p.cu_rows ? (int64_t)p.cu_rows[bh] : (int64_t)bh * nrows;
+
+  const uint16_t* kb = reinterpret_cast<const uint16_t*>(p.kptr) + (int64_t)b * p.ks_b + (int64_t)hk * p.ks_h + chunk * 8;
+  const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.vptr) + (int64_t)b * p.vs_b + (int64_t)hk * p.vs_h + chunk * 8;
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int r = r_blk + j * SLOTS + slot;
