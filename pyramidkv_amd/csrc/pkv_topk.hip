@@ -438,6 +438,191 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
         return;
       }
     }
+    // ---- Round 6 - rows that are mostly ZERO (fp16 at long context: most window probabilities underflow; fewer than k chunks
+    //      hold anything above zero's histogram bin, and the k-th value is zero or a subnormal tied thousands of times).  x* then
+    //      sits at or below zero's bin, every chunk passes the prefilter above and the attempt gives up - such rows used to
+    //      take the full path (20 us instead of 7).  They are decided here with the same machinery and the EXACT prefilter
+    //      "key > zero": the chunks holding a positive score (a few dozen) are staged, their positive keys counting-sorted by
+    //      key bucket (32 codes wide: the positive scores of a whole row, not a band under the maximum) and ranked inside their
+    //      bucket - rank == output position; all of them are selected when there are fewer than k - and the rest of the
+    //      selection is the lowest-index zeros, which is what (value desc, index asc) takes: ONE wave at a time walks its chunks
+    //      in index order (the first wave's first chunk usually holds them all; the other waves wait at a barrier, so its
+    //      instructions cost 4 cycles, not 16).  Too many positive keys, or too few zeros (negative scores): the full path.
+    //      This code sits BEHIND the ordinary attempt on purpose: in front of it, it cost ordinary rows 0.25-0.5 us. ----
+    {
+      const uint32_t zkey = order_key<T>((uint16_t)0);
+      if (xstar <= zkey) {
+        // bit j: chunk (j, lane) holds a key above zero.  Not carried over from the attempt above (one more live register and two
+        // more instructions per chunk there cost ordinary rows 0.2 us): the chunk maxima are read again where finalize_kernel
+        // left them (L2-hot), or taken from the raw scores (callers without chunk maxima).
+        uint32_t pos_bits = 0;
+        if (use_cmax) {
+          const uint16_t* cmp = reinterpret_cast<const uint16_t*>(p.cmax) + (int64_t)row * p.cmax_stride + (seg_off >> 3);
+          uint16_t cz[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < niter) {
+              const int c = wave * (Lw >> 3) + j * 64 + lane;
+              cz[j] = cmp[c < nch ? c : 0];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < niter) {
+              const int c = wave * (Lw >> 3) + j * 64 + lane;
+              pos_bits |= (c < nch && order_key<T>(cz[j]) > zkey ? 1u : 0u) << j;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < niter) {
+              const int base = wave * Lw + j * 512 + lane * 8;
+              uint32_t m = 0;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                uint32_t rw = raw[j].w[q];
+                asm volatile("" : "+v"(rw));                       // recomputed, not kept: see the zero walk below
+                const uint32_t kk = order_key_pk<T>(rw);
+                const uint32_t lo = (base + 2 * q < L) ? (kk & 0xffffu) : 0u, hi = (base + 2 * q + 1 < L) ? (kk >> 16) : 0u;
+                m = m > lo ? m : lo;
+                m = m > hi ? m : hi;
+              }
+              pos_bits |= (m > zkey ? 1u : 0u) << j;
+            }
+          }
+        }
+        __syncthreads();                                           // the attempt above is done with miscu[4] and HB
+        if (tid == 0) miscu[4] = 0;
+        reinterpret_cast<uint2*>(HB)[tid] = make_uint2(0u, 0u);
+        __syncthreads();
+        {
+          uint32_t npass = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < niter) npass += (uint32_t)__popcll(__ballot((pos_bits >> j) & 1u));
+          uint32_t slot0 = 0;
+          if (lane == 0 && npass) slot0 = atomicAdd(&miscu[4], npass);
+          slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < niter) {
+              const bool pass = (pos_bits >> j) & 1u;
+              const uint64_t mk = __ballot(pass);
+              if (mk != 0ull) {
+                const int c = wave * (Lw >> 3) + j * 64 + lane;
+                const uint32_t q = slot0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                if (pass && q < (uint32_t)pmax) { stage_raw[q] = raw[j].v; stage_id[q] = (uint16_t)c; }
+                slot0 += (uint32_t)__popcll(mk);
+              }
+            }
+          }
+        }
+        __syncthreads();
+        const uint32_t Pz = miscu[4];
+        if (Pz <= 512u && Pz <= (uint32_t)pmax) {                  // at most 4096 staged keys: four per thread
+          constexpr int ZSH = 5;                                   // (65535 - zkey) >> 5 < 2048 buckets
+          const uint32_t xs = zkey + 1u;
+          const uint16_t* stage_h = reinterpret_cast<const uint16_t*>(stage_raw);
+          const int nslots = (int)Pz * 8;
+          uint32_t comp[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            comp[i] = 0u;
+            const int sl = tid + i * TK_THREADS;
+            if (sl < nslots) {
+              const uint32_t key = order_key<T>(stage_h[sl]);
+              const uint32_t idx = (uint32_t)stage_id[sl >> 3] * 8u + (uint32_t)(sl & 7);
+              if ((int)idx < L && key >= xs) {
+                comp[i] = (key << 16) | (0xffffu - idx);
+                atomicAdd(&HB[TK2_NB - 1 - (int)((key - xs) >> ZSH)], 1u);
+              }
+            }
+          }
+          __syncthreads();
+          const uint2 hb = reinterpret_cast<const uint2*>(HB)[tid];
+          const uint32_t own = hb.x + hb.y;
+          const uint32_t incl = wave_incl_scan_u32(own);
+          if (lane == 63) wcnt[16 + wave] = incl;
+          __syncthreads();
+          const uint32_t wt = lane < TK_WAVES ? wcnt[16 + lane] : 0u;
+          const uint32_t wincl = wave_incl_scan_u32(wt);
+          const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)wincl, 63);
+          const uint32_t lower = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wave);
+          if (C <= (uint32_t)TK2_CMAX) {
+            const uint32_t bs = lower + incl - own;
+            reinterpret_cast<uint2*>(HB)[tid] = make_uint2(bs, bs + hb.x);
+            if (tid == 0) miscu[6] = C < (uint32_t)k ? (uint32_t)k - C : 0u;     // zeros still to be found
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (comp[i] != 0u) {
+                const uint32_t dst = atomicAdd(&HB[TK2_NB - 1 - (int)(((comp[i] >> 16) - xs) >> ZSH)], 1u);
+                tmpl[dst] = comp[i];
+              }
+            }
+            if (tid < 4) tmpl[C + tid] = 0u;
+            __syncthreads();
+            for (int i = tid; i < (int)C; i += TK_THREADS) {       // HB[d] is now the END of bucket d: rank inside the bucket
+              const uint32_t mine = tmpl[i];
+              const uint32_t d = TK2_NB - 1 - (((mine >> 16) - xs) >> ZSH);
+              const uint32_t st = d ? HB[d - 1] : 0u, en = HB[d];
+              const uint32_t a0 = st & ~3u;
+              uint32_t rank = a0;
+              for (uint32_t jj = a0; jj < en; jj += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(tmpl + jj);
+                rank += (uint32_t)(v.x > mine) + (uint32_t)(v.y > mine) + (uint32_t)(v.z > mine) + (uint32_t)(v.w > mine);
+              }
+              if (rank < (uint32_t)k) emit((int)rank, mine);
+            }
+            // positions C .. k-1: the first k - C zeros in index order, one wave at a time
+            const uint32_t need = C < (uint32_t)k ? (uint32_t)k - C : 0u;
+            for (int w2 = 0; w2 < TK_WAVES; ++w2) {
+              const uint32_t rem = miscu[6];                       // workgroup-uniform
+              if (rem == 0u) break;
+              if (wave == w2) {
+                uint32_t found = need - rem;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  if (j < niter && found < need) {                 // wave-uniform
+                    int base = wave * Lw + j * 512 + lane * 8;
+                    asm volatile("" : "+v"(base));                 // nothing of this body is hoisted out of the wave loop (it was: 90 spilled registers)
+                    uint32_t m = 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                      uint32_t rw = raw[j].w[q];
+                      asm volatile("" : "+v"(rw));
+                      const uint32_t kk = order_key_pk<T>(rw);
+                      m |= ((kk & 0xffffu) == zkey && base + 2 * q < L ? 1u : 0u) << (2 * q);
+                      m |= ((kk >> 16) == zkey && base + 2 * q + 1 < L ? 1u : 0u) << (2 * q + 1);
+                    }
+                    const uint32_t cnt = (uint32_t)__popc(m);
+                    const uint32_t inc2 = wave_incl_scan_u32(cnt);
+                    uint32_t r = found + inc2 - cnt;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                      if ((m >> e) & 1u) {
+                        if (r < need) emit((int)(C + r), (zkey << 16) | (0xffffu - (uint32_t)(base + e)));
+                        ++r;
+                      }
+                    }
+                    found += (uint32_t)__builtin_amdgcn_readlane((int)inc2, 63);
+                  }
+                }
+                if (lane == 0) miscu[6] = found >= need ? 0u : need - found;
+              }
+              __syncthreads();
+            }
+            if (miscu[6] == 0u) {
+              PKV_STAMP(6);
+              if (PKV_WGTRACE(p) && tid == 0) { PKV_WGTRACE(p)[2 * (131072 + row)] = t_start; PKV_WGTRACE(p)[2 * (131072 + row) + 1] = wall_clock64(); }
+              if (ADA) ada_epilogue();
+              return;
+            }
+          }
+        }
+      }
+    }
     // heavy ties: exact full path.  Its key table and counters start from scratch.
     __syncthreads();
     transform_all();

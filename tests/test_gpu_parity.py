@@ -185,6 +185,51 @@ def test_topk_adversarial(P, dt):
     _topk_check(P, s, 10)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_topk_rows_that_are_mostly_zero(P, dt):
+    """Round 6: rows whose k-th value is ZERO, tied thousands of times (fp16 at long context: most window probabilities
+    underflow) take the small-k path's zero branch - the positive scores ranked as always, then the lowest-index zeros, which
+    is torch.topk's (value desc, index asc) order - instead of the full path.  Every way that branch can start and end:
+    fewer positives than k / exactly k - 1 / k / more than k but in fewer than k chunks, an all-zero row, -0.0 among the zeros,
+    subnormal positives in zero's own histogram bin, negative scores with enough zeros and with too few (the full path), rows
+    of 32 760 / 8 184 / 600 scores, max-pooled runs, and the per-chunk maxima handed over by finalize (through compress)."""
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(6)
+    tiny = 6e-8 if dt == "fp16" else 1e-40                      # subnormal positives (same 8-code bin as zero)
+    for L in (32760, 8184, 600):
+        for npos in (0, 1, 17, 119, 120, 121, 300, 900):
+            if npos > L // 2:
+                continue
+            s = torch.zeros(3, L)
+            for r in range(3):
+                pos = torch.randperm(L, generator=g)[:npos]
+                s[r, pos] = torch.rand(npos, generator=g) * 0.5 + 1e-4
+            if npos >= 17:
+                s[1, torch.randperm(L, generator=g)[:7]] = tiny           # subnormals: positive, ranked above every zero
+                s[2, :40] = 0.0                                           # the first zeros of row 2 are the selected ones
+            s[0, torch.randperm(L, generator=g)[:50]] = -0.0              # equal to +0.0
+            for k in (1, 64, 120, 234, 512):
+                if k <= L:
+                    _topk_check(P, s.to(tdt), k)
+        # positives bunched into few chunks: fewer than k chunk maxima above zero, more than k positive keys
+        s = torch.zeros(2, L)
+        s[:, 1000 % L: 1000 % L + 400] = torch.rand(2, 400, generator=g) + 0.01 if L > 1400 else 0.0
+        _topk_check(P, s.to(tdt), 120)
+        _topk_check(P, s.to(tdt), 512 if L >= 512 else L)
+        # negative scores: enough zeros (zero is still the k-th value) / too few zeros (the k-th value is negative)
+        s = -torch.rand(2, L, generator=g)
+        s[:, torch.randperm(L, generator=g)[:200]] = 0.0
+        s[:, torch.randperm(L, generator=g)[:30]] = 0.3
+        _topk_check(P, s.to(tdt), 120)
+        _topk_check(P, s.to(tdt), 400 if L >= 400 else L)
+    # what the path is for: sink-distribution window scores in fp16, all stages through compress (chunk maxima from finalize)
+    q, k, v = make_qkv(1, 8, 32768, 128, "fp16", "sink", 66)
+    sc = P.ops.score_window(q.to(DEV), k.to(DEV), 8, "maxpool", 7).cpu()
+    for kk in (17, 120, 234, 504):
+        _, _, idx = P.ops.compress(q.to(DEV), k.to(DEV), v.to(DEV), 8, kk, "maxpool", 7, return_indices=True)
+        assert torch.equal(idx.cpu().long(), O.topk_canonical(sc, kk)), kk
+
+
 def test_topk_small_and_strided(P):
     g = torch.Generator().manual_seed(1)
     for L in (1, 2, 7, 8, 9, 63, 64, 65, 511, 513):
