@@ -27,6 +27,8 @@ constexpr size_t TK_LDS_LIMIT = 160 * 1024;
 constexpr int TK2_PMAX = 2048;           // staged chunks (16 key slots per thread)
 constexpr int TK2_CMAX = 4096;           // candidates
 constexpr int TK2_NB = 2048;             // key buckets of the counting sort
+constexpr int TK2_BMAX = 512;            // a bucket may hold at most this many candidates: ranking inside a bucket is quadratic (round 6: a row
+                                         // with ~1000 candidates on one fp16 subnormal value took 55 us here, 2x the full path it now takes)
 
 // LDS layout: keys u16[16*Lw] | X u32[max(8192,kpad)] | hist u32[256] | misc u32[64] | X2 u32[8192] (if it fits)
 size_t topk_lds_bytes(int L, int k, int* Lw_out, int* kpad_out) {
@@ -388,15 +390,19 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
       const uint2 hb = reinterpret_cast<const uint2*>(HB)[tid];
       const uint32_t own = hb.x + hb.y;
       const uint32_t incl = wave_incl_scan_u32(own);
-      if (lane == 63) wcnt[16 + wave] = incl;
+      // bit 31 of the wave's total: one of its buckets is too crowded to be ranked quadratically (TK2_BMAX)
+      const uint32_t crowded = __ballot(hb.x > (uint32_t)TK2_BMAX || hb.y > (uint32_t)TK2_BMAX) != 0ull ? 0x80000000u : 0u;
+      if (lane == 63) wcnt[16 + wave] = incl | crowded;
       __syncthreads();
       // cross-wave offsets: lane w reads the total of wave w, one wave scan gives every wave its base and the grand total
-      const uint32_t wt = lane < TK_WAVES ? wcnt[16 + lane] : 0u;
+      const uint32_t wraw = lane < TK_WAVES ? wcnt[16 + lane] : 0u;
+      const bool crowd = __ballot((wraw >> 31) != 0u) != 0ull;
+      const uint32_t wt = wraw & 0x7fffffffu;
       const uint32_t wincl = wave_incl_scan_u32(wt);
       const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)wincl, 63);
       const uint32_t lower = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wave);
       if (PKV_TRACE(p) && tid == 0 && row == 0) PKV_TRACE(p)[15] = C;
-      ok2 = C <= (uint32_t)TK2_CMAX && C >= (uint32_t)k;
+      ok2 = C <= (uint32_t)TK2_CMAX && C >= (uint32_t)k && !crowd;
       if (ok2) {
         const uint32_t bs = lower + incl - own;
         reinterpret_cast<uint2*>(HB)[tid] = make_uint2(bs, bs + hb.x);
@@ -543,13 +549,16 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
           const uint2 hb = reinterpret_cast<const uint2*>(HB)[tid];
           const uint32_t own = hb.x + hb.y;
           const uint32_t incl = wave_incl_scan_u32(own);
-          if (lane == 63) wcnt[16 + wave] = incl;
+          const uint32_t crowded = __ballot(hb.x > (uint32_t)TK2_BMAX || hb.y > (uint32_t)TK2_BMAX) != 0ull ? 0x80000000u : 0u;
+          if (lane == 63) wcnt[16 + wave] = incl | crowded;
           __syncthreads();
-          const uint32_t wt = lane < TK_WAVES ? wcnt[16 + lane] : 0u;
+          const uint32_t wraw = lane < TK_WAVES ? wcnt[16 + lane] : 0u;
+          const bool crowd = __ballot((wraw >> 31) != 0u) != 0ull;
+          const uint32_t wt = wraw & 0x7fffffffu;
           const uint32_t wincl = wave_incl_scan_u32(wt);
           const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)wincl, 63);
           const uint32_t lower = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wave);
-          if (C <= (uint32_t)TK2_CMAX) {
+          if (C <= (uint32_t)TK2_CMAX && !crowd) {
             const uint32_t bs = lower + incl - own;
             reinterpret_cast<uint2*>(HB)[tid] = make_uint2(bs, bs + hb.x);
             if (tid == 0) miscu[6] = C < (uint32_t)k ? (uint32_t)k - C : 0u;     // zeros still to be found

@@ -222,6 +222,20 @@ def test_topk_rows_that_are_mostly_zero(P, dt):
         s[:, torch.randperm(L, generator=g)[:30]] = 0.3
         _topk_check(P, s.to(tdt), 120)
         _topk_check(P, s.to(tdt), 400 if L >= 400 else L)
+    # crowded key buckets (round 6: ranking inside a bucket is quadratic; beyond 512 candidates in one bucket the small-k paths
+    # hand the row to the full path): a plateau of 1500 equal scores across the k-th position, and positives on an 11-value grid
+    L = 32760
+    s = torch.rand(2, L, generator=g) * 0.4
+    s[:, 100:150] = 1.0
+    s[:, 3000:4500] = 0.5
+    for k in (40, 120, 512):
+        _topk_check(P, s.to(tdt), k)
+    s = torch.zeros(2, L)
+    for r in range(2):
+        pos = torch.randperm(L, generator=g)[:2000]
+        s[r, pos] = torch.randint(1, 12, (2000,), generator=g).float() * (2.0 ** -24 if dt == "fp16" else 2.0 ** -133)
+    for k in (120, 504):
+        _topk_check(P, s.to(tdt), k)
     # what the path is for: sink-distribution window scores in fp16, all stages through compress (chunk maxima from finalize)
     q, k, v = make_qkv(1, 8, 32768, 128, "fp16", "sink", 66)
     sc = P.ops.score_window(q.to(DEV), k.to(DEV), 8, "maxpool", 7).cpu()
