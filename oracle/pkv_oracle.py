@@ -120,7 +120,8 @@ def window_score_one_product_moved(query_states, key_states, window_size: int, b
     q_r . k_j of :317 - a model-dtype value, i.e. an fp32 accumulation rounded once - is rounded to its NEIGHBOUR instead:
     the only freedom two correct implementations of :317 have (the accumulation order of the 128 terms; ATen's CPU kernel
     and an MFMA disagree on it for products that sit at a rounding midpoint).  Returns (score as computed here without any
-    move, [(window_row, step, score), ...] for the 2w single moves).  16-bit tensors only."""
+    move, [(window_row, step, score), ...] for the 2w single moves of the position's own products, followed by the 2w single
+    moves of each row's MAXIMUM - round 6).  16-bit tensors only."""
     w = window_size
     T = query_states.dtype
     head_dim = query_states.shape[-1]
@@ -147,6 +148,26 @@ def window_score_one_product_moved(query_states, key_states, window_size: int, b
             A = _scale(P1[None, None], head_dim, scale_mode)[0, 0].clone()
             if S - w <= j:
                 raise ValueError("position inside the observation window")
+            row_mask = torch.zeros(S, dtype=torch.float32)
+            row_mask[-w:] = mask[r]
+            A[0] += row_mask
+            pr = F.softmax(A, dim=-1, dtype=torch.float32).to(T)[0, j]
+            col = base_col.clone()
+            col[r, 0] = pr
+            moved.append((r, step, reduced(col)))
+    # Round 6: the same single move applied to the row's MAXIMUM instead of the position's own product.  On attention-sink rows
+    # the maximum is one large logit (spacing 2^-5 in fp16 around 40): moving it moves the row's whole normalisation, i.e. every
+    # position of that row by the same few per cent (tools/probes/sink_score_diff.py).
+    A0 = _scale(P0[None, None], head_dim, scale_mode)[0, 0].clone()
+    A0[-w:, -w:] += mask
+    for r in range(w):
+        jm = int(A0[r].float().argmax())
+        if jm == j:
+            continue                                            # already among the moves above
+        for step in (-1, 1):
+            P1 = P0[r:r + 1].clone()
+            P1[0, jm] = _neighbour(P0[r, jm], step)
+            A = _scale(P1[None, None], head_dim, scale_mode)[0, 0].clone()
             row_mask = torch.zeros(S, dtype=torch.float32)
             row_mask[-w:] = mask[r]
             A[0] += row_mask

@@ -17,7 +17,7 @@ def test_replay_without_a_move_is_the_oracle(dt, red):
         want = O.window_scores(q, k, w, red)
         for (b, h, j) in ((0, 1, 0), (1, 0, 100), (1, 1, 300 - w - 1)):
             base, moved = O.window_score_one_product_moved(q, k, w, b, h, j, red)
-            assert base == want[b, h, j] and len(moved) == 2 * w
+            assert base == want[b, h, j] and 2 * w <= len(moved) <= 4 * w       # own products, then every row's maximum (round 6)
     want = O.h2o_scores(q, k, 8)
     base, moved = O.h2o_score_one_product_moved(q, k, 8, 1, 0, 17)
     assert base == want[1, 0, 17] and len(moved) == 16

@@ -27,3 +27,17 @@ for dt in ("fp16", "bf16"):
                 "worst_head_ulp_hist": np.bincount(d[worst][m].clip(0, 8)).tolist() if m.any() else None,
                 "worst_head_want_gt_got": int((wb[worst][m] > gb[worst][m]).sum())}
 print(json.dumps(res, indent=1))
+
+# are the scores beyond 1 ulp explained by ONE moved product (the position's own, or - round 6 - the row's maximum)?
+import score_bar
+for dt in ("fp16",):
+    S, Hq, Hkv, w = 8192, 32, 8, 8
+    g = Hq // Hkv
+    q, k8, v8 = make_qkv(1, Hq, S, 128, dt, "sink", 4100 + S)
+    k_un = k8[:, ::g].contiguous()
+    k_exp = k_un[:, :, None].expand(1, Hkv, g, S, 128).reshape(1, Hq, S, 128).contiguous()
+    for red in ("sum", "mean"):
+        got = P.ops.score_window(q.cuda(), k_un.cuda(), w, None, 1, red, kv_group=g).cpu()
+        want = O.window_scores(q, k_exp, w, red)
+        n, exact, near, unexplained, pos = score_bar.explain_window_scores(q, k_exp, w, got, want, red, limit=200)
+        print(json.dumps({"explain_%s_%s" % (dt, red): {"beyond_1ulp": n, "reproduced_exactly": exact, "reproduced_within_1ulp": near, "unexplained": unexplained[:5]}}))
