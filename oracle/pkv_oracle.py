@@ -102,6 +102,37 @@ def window_scores(query_states, key_states, window_size: int, reduce: str = "sum
     return sl.sum(dim=-2) if reduce == "sum" else sl.mean(dim=-2)
 
 
+def window_scores_row_with_product_moved(query_states, key_states, window_size: int, b: int, h: int, r: int, j: int, step: int,
+                                         reduce: str = "sum", scale_mode: str = "div"):
+    """``window_scores(...)[b, h, :]`` when the ONE product q_r . k_j of :317 (window row r, key j) is rounded to its neighbour
+    (`step` = -1 / +1) - the WHOLE score row of the head, not only position j: where a single key carries a noticeable share of a
+    row's softmax mass (attention-sink-like rows: p_j ~ 0.1), moving its logit by one step moves the row's normaliser Z by
+    ~p_j x 1.5 %, i.e. every other probability of that row by about one unit of the last place (round 6: fp16 sink inputs,
+    S = 8192 - one product 2.6e-6 below a rounding midpoint, 265 of 8184 scores of the head off by 1-2 units and the key itself by
+    19, all reproduced exactly by this replay; tools/probes/sink_row_probe.py)."""
+    w, T, head_dim = window_size, query_states.dtype, query_states.shape[-1]
+    qw = query_states[b, h, -w:, :]
+    kk = key_states[b, h]
+    S = kk.shape[0]
+    P0 = torch.matmul(qw[None, None], kk.transpose(0, 1)[None, None])[0, 0].clone()     # [w, S] model dtype (:317)
+    P0[r, j] = _neighbour(P0[r, j], step)
+    A = _scale(P0[None, None], head_dim, scale_mode)[0, 0].clone()
+    A[-w:, -w:] += _corner_mask(w, T, P0.device)                                        # :322-324
+    col = F.softmax(A, dim=-1, dtype=torch.float32).to(T)[:, :S - w]                    # :326
+    return col.sum(dim=-2) if reduce == "sum" else col.mean(dim=-2)                     # :327 / :661
+
+
+def window_heavy_keys(query_states, key_states, window_size: int, b: int, h: int, n: int = 3, scale_mode: str = "div"):
+    """[(window row r, key j), ...]: the n largest logits of every window row of head (b, h) - the keys whose products can drag a
+    row's normaliser along when they move (see window_scores_row_with_product_moved)."""
+    w, T, head_dim = window_size, query_states.dtype, query_states.shape[-1]
+    P0 = torch.matmul(query_states[b, h, -w:, :][None, None], key_states[b, h].transpose(0, 1)[None, None])[0, 0]
+    A = _scale(P0[None, None], head_dim, scale_mode)[0, 0].clone()
+    A[-w:, -w:] += _corner_mask(w, T, P0.device)
+    top = A.float().topk(min(n, A.shape[-1]), dim=-1).indices
+    return [(r, int(j)) for r in range(w) for j in top[r].tolist()]
+
+
 def _neighbour(x: torch.Tensor, step: int) -> torch.Tensor:
     """The model-dtype value next above (step > 0) / below (step < 0) the finite 16-bit scalar tensor x."""
     b = int(x.reshape(1).view(torch.int16).item()) & 0xffff
