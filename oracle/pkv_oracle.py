@@ -348,6 +348,29 @@ def merge_kv(key_states, value_states, indices: torch.Tensor, window_size: int, 
         scatter-reduced (mean, include_self) onto the pivots (:161)."""
     if merge != "pivot":
         raise ValueError('Merge method not supported')                                            # :164
+    head_dim = key_states.shape[-1]
+    drop_keys, drop_values, k_hh_recent, v_hh_recent, max_indices = _merge_front(key_states, value_states, indices, window_size)
+    merged_indices = max_indices.unsqueeze(-1).repeat(1, 1, 1, head_dim)                          # :156
+    k_hh_selected = torch.gather(input=k_hh_recent, dim=2, index=merged_indices)
+    k_hh_merged = (drop_keys + k_hh_selected) / 2                                                 # :158
+    k_out = torch.scatter_reduce(input=k_hh_recent, dim=2, index=merged_indices, src=k_hh_merged, reduce='mean',
+                                 include_self=True)                                               # :159
+    v_hh_selected = torch.gather(input=v_hh_recent, dim=2, index=merged_indices)
+    v_hh_merged = (drop_values + v_hh_selected) / 2
+    v_out = torch.scatter_reduce(input=v_hh_recent, dim=2, index=merged_indices, src=v_hh_merged, reduce='mean',
+                                 include_self=True)                                               # :162
+    return k_out, v_out
+
+
+def merge_pivots(key_states, value_states, indices: torch.Tensor, window_size: int):
+    """The pivots of ``merge_kv`` - ``similarity.max(dim=-1)`` of :150-151 by the very same ops: int64 [B, H, dropped rows], the
+    kept-row number (KEY order [window, selected]) every dropped row merges into.  tests/merge_bar.py compares the kernel's
+    pivots with THESE (an fp32 replica of the fp16 / bf16 ``@`` accumulates in another order and is not the reference)."""
+    return _merge_front(key_states, value_states, indices, window_size)[4]
+
+
+def _merge_front(key_states, value_states, indices, window_size):
+    """:121-151 of merge_kv: the dropped rows, the kept rows in the reference's two orders, and the pivots."""
     bsz, num_heads, k_len, head_dim = key_states.shape
     idx = indices.to(torch.int64).unsqueeze(-1).expand(-1, -1, -1, head_dim)
     selected_keys = key_states.gather(dim=2, index=idx)                                           # :125
@@ -366,16 +389,7 @@ def merge_kv(key_states, value_states, indices: torch.Tensor, window_size: int, 
     similarity = (drop_keys / torch.norm(drop_keys, dim=-1).unsqueeze(-1).repeat(1, 1, 1, head_dim)) @ \
         ((k_hh_recent / (torch.norm(k_hh_recent, dim=-1).unsqueeze(-1).repeat(1, 1, 1, head_dim))).transpose(-1, -2))   # :150
     _, max_indices = similarity.max(dim=-1)                                                       # :151
-    merged_indices = max_indices.unsqueeze(-1).repeat(1, 1, 1, head_dim)                          # :156
-    k_hh_selected = torch.gather(input=k_hh_recent, dim=2, index=merged_indices)
-    k_hh_merged = (drop_keys + k_hh_selected) / 2                                                 # :158
-    k_out = torch.scatter_reduce(input=k_hh_recent, dim=2, index=merged_indices, src=k_hh_merged, reduce='mean',
-                                 include_self=True)                                               # :159
-    v_hh_selected = torch.gather(input=v_hh_recent, dim=2, index=merged_indices)
-    v_hh_merged = (drop_values + v_hh_selected) / 2
-    v_out = torch.scatter_reduce(input=v_hh_recent, dim=2, index=merged_indices, src=v_hh_merged, reduce='mean',
-                                 include_self=True)                                               # :162
-    return k_out, v_out
+    return drop_keys, drop_values, k_hh_recent, v_hh_recent, max_indices
 
 
 def merge_kv_explicit(key_states, value_states, indices: torch.Tensor, window_size: int):

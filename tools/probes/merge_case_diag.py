@@ -39,6 +39,12 @@ drop = [p for p in range(S) if p not in union]
 res["drop_list_equal"] = drop == drop_k.tolist()
 tdt = ke.dtype
 rnd = lambda x: x.to(tdt).float()
+piv_ref = O.merge_pivots(ke, ve, idx, w).numpy()
+from merge_bar import check_merge
+try:
+    res["check_merge_moved"] = check_merge(ops, ke, ve, idx, w, km, vm, "diag")
+except AssertionError as e:
+    res["check_merge_assertion"] = str(e.args)[:300]
 for b in range(B):
     for h in range(H):
         Kf = ke[b, h].float()
@@ -46,8 +52,8 @@ for b in range(B):
         tgt = torch.cat([Kf[S - w:], Kf[sel]], 0)
         unit = lambda X: rnd(X / rnd(torch.sqrt((X * X).sum(-1)))[:, None])
         ud, ut = unit(Kf[drop]), unit(tgt)
-        sim = rnd(ud @ ut.T)                                     # the oracle's similarities (ATen CPU GEMM order)
-        piv_o = (sim == sim.max(-1, keepdim=True).values).float().argmax(-1).numpy()
+        sim = rnd(ud @ ut.T)                                     # an fp32 replica of the similarities (for the printed values only)
+        piv_o = piv_ref[b, h]                                    # the reference's own pivots (ATen's model-dtype matmul)
         pk = piv_k[b * H + h]
         diff = np.nonzero(piv_o != pk)[0]
         rows = []
@@ -60,3 +66,17 @@ for b in range(B):
         res["heads"].append({"b": b, "h": h, "pivots_differ": int(len(diff)), "of": int(len(pk)), "examples": rows,
                              "k_rows_differ": int((km[b, h].cpu() != kmr[b, h]).any(-1).sum()), "v_rows_differ": int((vm[b, h].cpu() != vmr[b, h]).any(-1).sum())})
 print(json.dumps(res, indent=1))
+
+# ---- rows whose K or V differ although every pivot agrees: the scatter-mean arithmetic itself ----
+detail = []
+for b in range(B):
+    for h in range(H):
+        dk = (km[b, h].cpu().view(torch.int16) != kmr[b, h].view(torch.int16))
+        dv = (vm[b, h].cpu().view(torch.int16) != vmr[b, h].view(torch.int16))
+        for j in torch.nonzero(dk.any(-1) | dv.any(-1)).flatten().tolist()[:4]:
+            pk = piv_k[b * H + h]
+            detail.append({"b": b, "h": h, "kept_row": j, "k_elems_differ": int(dk[j].sum()), "v_elems_differ": int(dv[j].sum()),
+                           "rows_merged_into_it_key_order": int((pk == j).sum()),
+                           "first_k_diff": [(int(e), float(km[b, h, j, e]), float(kmr[b, h, j, e])) for e in torch.nonzero(dk[j]).flatten().tolist()[:3]],
+                           "first_v_diff": [(int(e), float(vm[b, h, j, e]), float(vmr[b, h, j, e])) for e in torch.nonzero(dv[j]).flatten().tolist()[:3]]})
+print(json.dumps({"rows_with_differences": detail[:12]}, indent=1))
