@@ -115,7 +115,12 @@ __device__ __forceinline__ void radix_pass(const uint32_t* src, uint32_t* dst, u
 // (:711), stored as order-preserving keys.  In the single-workgroup budget kernel the same arithmetic was 390 of 510
 // instructions per wave of its longest phase (16 waves on ONE CU: every instruction costs 16 cycles there).
 // A template parameter: the plain selection carries none of it.
-template <typename T, bool ADA>
+// NI (round 6): 512-key chunks per wave as a compile-time constant (1, 2 or 4; 0 = read from p.Lw: rows beyond 32 768 keys - eight
+// chunks fully unrolled need more than the kernel's 128 registers).  Every loop over a lane's
+// chunks is `for j < 8: if (j < niter)`: with a run-time niter that is eight scalar compare-and-branch pairs per loop, ~20 loops,
+// and eight condition masks the compiler keeps in scalar registers for all of them (the kernel sat at its 104-register limit and
+// spilled into the small-k path's loops once the zero-tied rows were added).  S = 4k / 8k / 16k / 32k rows are 1 / 1 / 2 / 4 chunks.
+template <typename T, bool ADA, int NI>
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
   const bool vec_ok = ((p.scores_stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.scores) & 15) == 0);
   const uint32_t inc = lane < 32 ? 1u : 65536u;
   const int cslot = lane & 31;
-  const int niter = Lw / 512;
+  const int niter = NI > 0 ? NI : Lw / 512;
 
 #define PKV_STAMP(i) do { if (PKV_TRACE(p) && tid == 0 && row == 0) PKV_TRACE(p)[i] = (unsigned long long)clock64(); } while (0)
   PKV_STAMP(0);
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkParams p) {
     //      This code sits BEHIND the ordinary attempt on purpose: in front of it, it cost ordinary rows 0.25-0.5 us. ----
     {
       const uint32_t zkey = order_key<T>((uint16_t)0);
-      if (xstar <= zkey) {
+      if (__builtin_expect(xstar <= zkey, 0)) {                      // cold: the register allocator keeps its spill code out of the attempt above
         // bit j: chunk (j, lane) holds a key above zero.  Not carried over from the attempt above (one more live register and two
         // more instructions per chunk there cost ordinary rows 0.2 us): the chunk maxima are read again where finalize_kernel
         // left them (L2-hot), or taken from the raw scores (callers without chunk maxima).
@@ -1065,7 +1070,13 @@ __global__ __launch_bounds__(TK_THREADS) void sort_rows_kernel(SortParams p) {
 
 hipError_t launch_topk(int dtype, int rows, const TopkParams& p, size_t lds, hipStream_t st) {
   const bool ada = p.list_out != nullptr;
-  auto fn = dtype == 0 ? (ada ? topk_kernel<BF16, true> : topk_kernel<BF16, false>) : (ada ? topk_kernel<F16, true> : topk_kernel<F16, false>);
+  const int ni = p.Lw / 512;
+  void (*fn)(TopkParams) = nullptr;
+#define PKV_TK(TT, AD)                                                                                                         \
+  fn = ni == 1 ? topk_kernel<TT, AD, 1> : ni == 2 ? topk_kernel<TT, AD, 2> : ni == 4 ? topk_kernel<TT, AD, 4> : topk_kernel<TT, AD, 0>
+  if (dtype == 0) { if (ada) PKV_TK(BF16, true); else PKV_TK(BF16, false); }
+  else            { if (ada) PKV_TK(F16, true); else PKV_TK(F16, false); }
+#undef PKV_TK
   if (lds > 64 * 1024) {
     hipError_t e = dyn_lds(reinterpret_cast<const void*>(fn), lds);
     if (e != hipSuccess) return e;
