@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 constexpr int FN_OUT = 1024;               // positions computed and written per workgroup (256 threads x 4)
 constexpr int FN_HALO = 8;                 // positions on either side (pool kernel <= 17)
 
-template <typename T>
+// W (round 6): the observation window as a compile-time constant (8 = the runners', 32 = the init_* default; 0 = read from p.w).
+// Four 256-thread workgroups per CU = 16 waves: every instruction of a wave costs ~16 cycles of wall time, and a run-time
+// window means row clamps, row weights and loop tests in every pass over the window rows.
+template <typename T, int W>
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   __shared__ __attribute__((aligned(16))) uint16_t sc[FN_OUT + 2 * FN_HALO];   // index = position - first position + 8
   __shared__ float rowM[128];           // window <= 128 (check_desc)
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 
   const int tid = threadIdx.x;
   const int bh = blockIdx.y;
-  const int w = p.w;
+  const int w = W > 0 ? W : p.w;
   const int L = p.S - w;
   const int64_t rowbase = (int64_t)bh * w;
 #define PKV_FSTAMP(i) do { if (PKV_TRACE(p) && tid == 0 && blockIdx.x == 1 && bh == 0) PKV_TRACE(p)[i] = (unsigned long long)clock64(); } while (0)
@@ -717,8 +720,14 @@ int finalize_blocks(int S, int w) { return (S - w + FN_OUT - 1) / FN_OUT; }
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st) {
   const int L = p.S - p.w;
   dim3 grid((L + FN_OUT - 1) / FN_OUT, p.B * p.H);
-  if (dtype == 0) PKV_KLAUNCH(finalize_kernel<BF16>, grid, dim3(256), 0, st, p);
-  else PKV_KLAUNCH(finalize_kernel<F16>, grid, dim3(256), 0, st, p);
+#define PKV_FIN(TT)                                                                                              \
+  do {                                                                                                         \
+    if (p.w == 8) PKV_KLAUNCH((finalize_kernel<TT, 8>), grid, dim3(256), 0, st, p);                            \
+    else if (p.w == 32) PKV_KLAUNCH((finalize_kernel<TT, 32>), grid, dim3(256), 0, st, p);                     \
+    else PKV_KLAUNCH((finalize_kernel<TT, 0>), grid, dim3(256), 0, st, p);                                     \
+  } while (0)
+  if (dtype == 0) PKV_FIN(BF16); else PKV_FIN(F16);
+#undef PKV_FIN
   return hipGetLastError();
 }
 
