@@ -6,12 +6,12 @@ libs = [a for a in sys.argv[1:] if a.endswith(".so")]
 rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
 for r in range(rounds):
     for lib in libs:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extras", "--no-parity"],
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--only-gqa-extra", "--no-parity"],
                              env=dict(os.environ, PKV_LIB=os.path.abspath(lib)), capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
             print(lib, "FAILED", out.stderr[-400:], flush=True)
             continue
         d = json.loads(line[0])
-        print(os.path.basename(lib), d["ms_per_step"], {k: v["avg_us"] for k, v in d["roofline_kernels"].items() if k in ("logits", "finalize", "topk", "gather")},
-              {"grid": [(g["B"], g["budget"], g["update_kv_us"]) for g in d.get("grid", [])]}, flush=True)
+        print(os.path.basename(lib), d["ms_per_step"], {k: v["avg_us"] for k, v in d["roofline_kernels"].items() if k in ("logits", "finalize", "topk", "gather", "logits_gqa4", "finalize_gqa4", "topk_gqa4")},
+              {"gqa_us_per_layer": (d.get("extras") or {}).get("unexpanded_gqa_us_per_layer")}, flush=True)
