@@ -265,7 +265,7 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
   fp.cmax = want_cmax ? ws + L.off_cmax : nullptr; fp.cmax_stride = L.Lp / 8;
   fp.trace = g_topk_trace ? g_topk_trace + 8 : nullptr;
   fp.wgtrace = g_wg_trace;
-  fp.rowsum_part = rowsum_part; fp.rowsum_np = finalize_blocks(d->S, d->window);
+  fp.rowsum_part = rowsum_part; fp.rowsum_np = finalize_blocks(d->S, d->window, d->B * d->H);
   {
     ProfScope ps(PKV_K_FINALIZE, st, true);
     hipError_t e = launch_finalize(d->dtype, fp, st);
@@ -759,7 +759,7 @@ int pkv_ada_select(const pkv_desc* d, const void* q, const void* k, int32_t base
   // finalize the row sums (one fp64 partial per workgroup), the selection every head's descending list of raw scores - and the
   // budgets are ONE single-workgroup launch
   const int Lpad = (M + 7) & ~7;
-  const int np = finalize_blocks(d->S, d->window);
+  const int np = finalize_blocks(d->S, d->window, d->B * d->H);
   const bool fused = !given_capacity && d->dtype != PKV_F32 && ada_fused_fits(H, M) && topk_fits(L, M) && np <= 128 && ada_fused() != 0;
   double* rowsum = reinterpret_cast<double*>(w + W.off_ada + 1024);           // [H][np] doubles inside the (then unused) count tables
   rc = do_score_window(d, q, k, scores, W.Lp, w, W, st, cm, fused ? rowsum : nullptr);

@@ -250,7 +250,7 @@ hipError_t launch_budget(int dtype, const BudgetParams& p, hipStream_t st);
 // (p.L entries per head at list[h * Lpad]); ada_fused_fits() = the lists of all heads fit one workgroup's LDS next to the counters
 bool ada_fused_fits(int H, int M);
 hipError_t launch_ada_fused(const BudgetParams& p, const void* list, int Lpad, hipStream_t st);
-int finalize_blocks(int S, int w);     // workgroups per (b, h) row of finalize_kernel = row-sum partials per head
+int finalize_blocks(int S, int w, int BH);     // workgroups per (b, h) row of finalize_kernel = row-sum partials per head (BH = B * H rows in the launch)
 hipError_t launch_ada_final(const BudgetParams& p, int32_t* cum_hi, int32_t* cum_lo, const int32_t* above_hi, hipStream_t st);
 hipError_t launch_budget_f32(const BudgetParams& p, hipStream_t st);      // fp32 score rows (pkv_f32.hip), ws: 1024 + 4*H*256*4 + 4*H*4 bytes
 int budget_f32_max_row();

@@ -181,14 +181,18 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsParams p) {
 // of a kernel that is bound by vector issue.  1024 outputs per workgroup give 32 / 16 / 8 / 4 workgroups per head at
 // S = 32k / 16k / 8k / 4k: whole multiples of the CU count for the BASELINE shapes (measured: 8.2 against 8.4 us at S = 32k).
 // ------------------------------------------------------------------------------------------------
-constexpr int FN_OUT = 1024;               // positions computed and written per workgroup (256 threads x 4)
 constexpr int FN_HALO = 8;                 // positions on either side (pool kernel <= 17)
 
 // W (round 6): the observation window as a compile-time constant (8 = the runners', 32 = the init_* default; 0 = read from p.w).
 // Four 256-thread workgroups per CU = 16 waves: every instruction of a wave costs ~16 cycles of wall time, and a run-time
 // window means row clamps, row weights and loop tests in every pass over the window rows.
-template <typename T, int W>
+// PPT (round 6): positions per thread, 4 or 8 (1024 or 2048 positions per workgroup).  A third of a workgroup's instructions do
+// not depend on the number of positions (the partial merge, the halo, the pooling set-up): with 8 positions per thread a head needs
+// half the workgroups and a third fewer instructions in all, and a CU holds 8 instead of 16 of its waves.
+template <typename T, int W, int PPT>
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
+  constexpr int FN_OUT = 256 * PPT;                                            // positions computed and written per workgroup
+  constexpr int NW = PPT / 2;                                                  // 32-bit words (pairs of scores) per thread and row
   __shared__ __attribute__((aligned(16))) uint16_t sc[FN_OUT + 2 * FN_HALO];   // index = position - first position + 8
   __shared__ float rowM[128];           // window <= 128 (check_desc)
   __shared__ float rowS[128];
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
   const unsigned long long t_start = PKV_WGTRACE(p) ? wall_clock64() : 0ull;
 
   const int p0 = blockIdx.x * FN_OUT;
-  const int s0 = p0 + tid * 4;
+  const int s0 = p0 + tid * PPT;
   const bool in_row = s0 < L;
   const uint16_t* lgp = reinterpret_cast<const uint16_t*>(p.logits) + rowbase * (int64_t)p.Sp + (in_row ? s0 : 0);
   // row statistics from the per-tile partials: M = max_t m_t, Z = sum_t l_t * exp(m_t - M).
@@ -262,19 +266,26 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
     const int pos = halo_pos(i < 2 * FN_HALO ? i : 0);
     halo_x0 = lgh[(int64_t)r * p.Sp + ((pos >= 0 && pos < L) ? pos : 0)];
   }
-  uint16_t ov[4];
+  uint16_t ov[PPT];
   if (in_row) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[PPT];
+#pragma unroll
+    for (int e = 0; e < PPT; ++e) acc[e] = 0.f;
     for (int rb = 0; rb < w; rb += 8) {
       // 8 rows per pass, all loads first.  Rows past w are clamped (re-read row w-1) and weighted 0:
       // no control flow between the loads and their uses, so they stay batched (one round trip).
-      uint2 u[8];
+      uint32_t u[8][NW];
       float M[8], RZ[8], wt[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = rb + j < w ? rb + j : w - 1;
-        const u32x2 t2 = *reinterpret_cast<const u32x2*>(lgp + (int64_t)r * p.Sp);
-        u[j] = make_uint2(t2.x, t2.y);
+        if constexpr (PPT == 8) {
+          const u32x4 t4 = *reinterpret_cast<const u32x4*>(lgp + (int64_t)r * p.Sp);
+          u[j][0] = t4.x; u[j][1] = t4.y; u[j][2] = t4.z; u[j][3] = t4.w;
+        } else {
+          const u32x2 t2 = *reinterpret_cast<const u32x2*>(lgp + (int64_t)r * p.Sp);
+          u[j][0] = t2.x; u[j][1] = t2.y;
+        }
         M[j] = rowM[r];
         RZ[j] = rowS[r];
         wt[j] = rb + j < w ? 1.0f : 0.0f;
@@ -282,10 +293,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         // two keys per packed instruction: x - M, exp, * (1/Z), round, accumulate (same operations as the scalar form)
-        const uint32_t uu[2] = {u[j].x, u[j].y};
+        const uint32_t* uu = u[j];
         const pkv_f32x2 mm = {M[j], M[j]}, rz = {RZ[j], RZ[j]}, ww = {wt[j], wt[j]};
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
+        for (int h2 = 0; h2 < NW; ++h2) {
           const pkv_f32x2 x = {Elem<T>::to_f32((uint16_t)(uu[h2] & 0xffffu)), Elem<T>::to_f32((uint16_t)(uu[h2] >> 16))};
           const pkv_f32x2 pr = pkv_exp_pair(x - mm) * rz;                           // fp32 softmax (:326)
           const uint32_t pk2 = round_pack2<T>(pr.x, pr.y);                          // .to(dtype)
@@ -297,19 +308,28 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
       }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < PPT; ++e) {
       const float v = (p.reduce == 1) ? (acc[e] / (float)w) : acc[e];             // mean (:661) or sum (:327)
       ov[e] = (s0 + e < L) ? Elem<T>::from_f32(v) : pad;
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ov[e] = pad;
+    for (int e = 0; e < PPT; ++e) ov[e] = pad;
   }
-  uint2 pk;
-  pk.x = (uint32_t)ov[0] | ((uint32_t)ov[1] << 16);
-  pk.y = (uint32_t)ov[2] | ((uint32_t)ov[3] << 16);
   PKV_FSTAMP(2);
-  *reinterpret_cast<uint2*>(sc + FN_HALO + tid * 4) = pk;
+  if constexpr (PPT == 8) {
+    uint4 pk;
+    pk.x = (uint32_t)ov[0] | ((uint32_t)ov[1] << 16);
+    pk.y = (uint32_t)ov[2] | ((uint32_t)ov[3] << 16);
+    pk.z = (uint32_t)ov[4] | ((uint32_t)ov[5] << 16);
+    pk.w = (uint32_t)ov[6] | ((uint32_t)ov[7] << 16);
+    *reinterpret_cast<uint4*>(sc + FN_HALO + tid * 8) = pk;
+  } else {
+    uint2 pk;
+    pk.x = (uint32_t)ov[0] | ((uint32_t)ov[1] << 16);
+    pk.y = (uint32_t)ov[2] | ((uint32_t)ov[3] << 16);
+    *reinterpret_cast<uint2*>(sc + FN_HALO + tid * 4) = pk;
+  }
   // ---- halo: positions p0-8 .. p0-1 and p0+1024 .. p0+1031, the same arithmetic, one (position, window row) task per thread
   //      and pass.  The w probabilities of a position sit in w consecutive lanes of ONE wave (w a power of two <= 64), go
   //      through LDS and are summed by the group's first lane in row order - the fp32 order of the main path. ----
@@ -370,21 +390,34 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
     PKV_WGTRACE(p)[2 * wg] = t_start; PKV_WGTRACE(p)[2 * wg + 1] = wall_clock64();
   }
   const bool writer = s0 < L;                                 // positions past the row write nothing
-  uint16_t res[4];
+  uint16_t res[PPT];
   const int half = p.pool_kernel >> 1;
   if (p.pool_kind == 0 || !writer) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) res[e] = ov[e];
+    for (int e = 0; e < PPT; ++e) res[e] = ov[e];
   } else {
-    // the 20 staged scores around this thread's 4 positions: 5 x 8-byte LDS reads issued together
-    float v[20];
+    // the PPT + 16 staged scores around this thread's positions: 8-byte (16-byte) LDS reads issued together
+    float v[PPT + 16];
+    if constexpr (PPT == 8) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const uint2 t = *reinterpret_cast<const uint2*>(sc + tid * 4 + i * 4);
-      v[i * 4 + 0] = Elem<T>::to_f32((uint16_t)(t.x & 0xffffu));
-      v[i * 4 + 1] = Elem<T>::to_f32((uint16_t)(t.x >> 16));
-      v[i * 4 + 2] = Elem<T>::to_f32((uint16_t)(t.y & 0xffffu));
-      v[i * 4 + 3] = Elem<T>::to_f32((uint16_t)(t.y >> 16));
+      for (int i = 0; i < 3; ++i) {
+        const uint4 t = *reinterpret_cast<const uint4*>(sc + tid * 8 + i * 8);
+        const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[i * 8 + 2 * q] = Elem<T>::to_f32((uint16_t)(tw[q] & 0xffffu));
+          v[i * 8 + 2 * q + 1] = Elem<T>::to_f32((uint16_t)(tw[q] >> 16));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const uint2 t = *reinterpret_cast<const uint2*>(sc + tid * 4 + i * 4);
+        v[i * 4 + 0] = Elem<T>::to_f32((uint16_t)(t.x & 0xffffu));
+        v[i * 4 + 1] = Elem<T>::to_f32((uint16_t)(t.x >> 16));
+        v[i * 4 + 2] = Elem<T>::to_f32((uint16_t)(t.y & 0xffffu));
+        v[i * 4 + 3] = Elem<T>::to_f32((uint16_t)(t.y >> 16));
+      }
     }
     // the runners' kernel sizes (run_longbench.py: maxpool 7, avgpool 5) get compile-time windows: the generic loop is 17
     // predicated taps per output, ~70 instructions per position
@@ -404,36 +437,40 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
     };
     if (p.pool_kind == 2 && half == 3) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) res[e] = pool_at(e, 3, true);
+      for (int e = 0; e < PPT; ++e) res[e] = pool_at(e, 3, true);
     } else if (p.pool_kind == 1 && half == 2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) res[e] = pool_at(e, 2, false);
+      for (int e = 0; e < PPT; ++e) res[e] = pool_at(e, 2, false);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) res[e] = pool_at(e, half, p.pool_kind == 2);
+      for (int e = 0; e < PPT; ++e) res[e] = pool_at(e, half, p.pool_kind == 2);
     }
   }
-  // per-chunk maxima (8 consecutive positions = an even/odd lane pair) for the top-k prefilter
+  // per-chunk maxima (8 consecutive positions: an even/odd lane pair, or - 8 positions per thread - the thread's own) for the top-k prefilter
   if (p.cmax) {
     float m4 = -INFINITY;
     uint16_t b4 = Elem<T>::neg_inf();
     if (writer) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < PPT; ++e) {
         const float x = Elem<T>::to_f32(res[e]);
         if (s0 + e < L && x > m4) { m4 = x; b4 = res[e]; }
       }
     }
-    const float mo = __shfl_xor(m4, 1, 64);
-    const uint32_t bo = __shfl_xor((uint32_t)b4, 1, 64);
-    if (writer && !(tid & 1))
-      reinterpret_cast<uint16_t*>(p.cmax)[(int64_t)bh * p.cmax_stride + (s0 >> 3)] = (mo > m4) ? (uint16_t)bo : b4;
+    if constexpr (PPT == 8) {
+      if (writer) reinterpret_cast<uint16_t*>(p.cmax)[(int64_t)bh * p.cmax_stride + (s0 >> 3)] = b4;
+    } else {
+      const float mo = __shfl_xor(m4, 1, 64);
+      const uint32_t bo = __shfl_xor((uint32_t)b4, 1, 64);
+      if (writer && !(tid & 1))
+        reinterpret_cast<uint16_t*>(p.cmax)[(int64_t)bh * p.cmax_stride + (s0 >> 3)] = (mo > m4) ? (uint16_t)bo : b4;
+    }
   }
   if (p.rowsum_part) {        // Ada-SnapKV: this workgroup's share of the sum over all scores of the row (:710), fp64
     double sa = 0.0;
     if (writer) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (s0 + e < L) sa += (double)Elem<T>::to_f32(res[e]);
+      for (int e = 0; e < PPT; ++e) if (s0 + e < L) sa += (double)Elem<T>::to_f32(res[e]);
     }
     sa = wave_sum_f64(sa);
     if ((tid & 63) == 0) rs_red[tid >> 6] = sa;
@@ -441,11 +478,20 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeParams p) {
     if (tid == 0) p.rowsum_part[(int64_t)bh * p.rowsum_np + blockIdx.x] = ((rs_red[0] + rs_red[1]) + rs_red[2]) + rs_red[3];
   }
   if (!writer) return;
-  uint2 ro;
-  ro.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
-  ro.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
   uint16_t* out = reinterpret_cast<uint16_t*>(p.scores) + (int64_t)bh * p.scores_stride + s0;
-  *reinterpret_cast<uint2*>(out) = ro;      // stride % 8 == 0, s0 % 4 == 0, stride >= roundup(L,8): aligned, in bounds
+  if constexpr (PPT == 8) {
+    uint4 ro;
+    ro.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+    ro.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+    ro.z = (uint32_t)res[4] | ((uint32_t)res[5] << 16);
+    ro.w = (uint32_t)res[6] | ((uint32_t)res[7] << 16);
+    *reinterpret_cast<uint4*>(out) = ro;    // stride % 8 == 0, s0 % 8 == 0, stride >= roundup(L,8): aligned, in bounds
+  } else {
+    uint2 ro;
+    ro.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+    ro.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+    *reinterpret_cast<uint2*>(out) = ro;    // stride % 8 == 0, s0 % 4 == 0, stride >= roundup(L,8): aligned, in bounds
+  }
   if (PKV_TRACE(p) && tid == 2 && blockIdx.x == 1 && bh == 0) PKV_TRACE(p)[4] = (unsigned long long)clock64();
 #undef PKV_FSTAMP
 }
@@ -723,19 +769,31 @@ hipError_t launch_logits(int dtype, const LogitsParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-int finalize_blocks(int S, int w) { return (S - w + FN_OUT - 1) / FN_OUT; }
+// positions per thread of finalize_kernel for a shape: 8 (2048 positions per workgroup) while that still leaves 512 workgroups
+// (two per CU), else 4.  Measured (tools/probes/finalize_ppt_probe.py, H = 32, window 8): B = 8, S = 32k 50.0 -> 44.5 us; B = 4 21.9 ->
+// 19.4; B = 8, S = 8k 11.9 -> 10.7; B = 1, S = 32k 7.2 -> 7.0; but B = 1, S = 8k 4.5 -> 4.9 and S = 4k 4.3 -> 4.5: a launch that
+// does not fill the chip is one latency chain, and the longer workgroup only stretches it.
+static int finalize_ppt(int S, int w, int BH) {
+  static int forced = [] { const char* v = getenv("PKV_FINALIZE_PPT"); return v && *v ? atoi(v) : 0; }();
+  if (forced == 4 || forced == 8) return forced;
+  const int64_t wgs8 = (int64_t)BH * ((S - w + 2047) / 2048);
+  return wgs8 >= 512 ? 8 : 4;
+}
+int finalize_blocks(int S, int w, int BH) { const int out = 256 * finalize_ppt(S, w, BH); return (S - w + out - 1) / out; }
 
 hipError_t launch_finalize(int dtype, const FinalizeParams& p, hipStream_t st) {
-  const int L = p.S - p.w;
-  dim3 grid((L + FN_OUT - 1) / FN_OUT, p.B * p.H);
-#define PKV_FIN(TT)                                                                                              \
+  const int ppt = finalize_ppt(p.S, p.w, p.B * p.H);
+  dim3 grid(finalize_blocks(p.S, p.w, p.B * p.H), p.B * p.H);
+#define PKV_FIN2(TT, PP)                                                                                         \
   do {                                                                                                         \
-    if (p.w == 8) PKV_KLAUNCH((finalize_kernel<TT, 8>), grid, dim3(256), 0, st, p);                            \
-    else if (p.w == 32) PKV_KLAUNCH((finalize_kernel<TT, 32>), grid, dim3(256), 0, st, p);                     \
-    else PKV_KLAUNCH((finalize_kernel<TT, 0>), grid, dim3(256), 0, st, p);                                     \
+    if (p.w == 8) PKV_KLAUNCH((finalize_kernel<TT, 8, PP>), grid, dim3(256), 0, st, p);                        \
+    else if (p.w == 32) PKV_KLAUNCH((finalize_kernel<TT, 32, PP>), grid, dim3(256), 0, st, p);                 \
+    else PKV_KLAUNCH((finalize_kernel<TT, 0, PP>), grid, dim3(256), 0, st, p);                                 \
   } while (0)
+#define PKV_FIN(TT) do { if (ppt == 8) PKV_FIN2(TT, 8); else PKV_FIN2(TT, 4); } while (0)
   if (dtype == 0) PKV_FIN(BF16); else PKV_FIN(F16);
 #undef PKV_FIN
+#undef PKV_FIN2
   return hipGetLastError();
 }
 
