@@ -236,7 +236,11 @@ int do_score_window(const pkv_desc* d, const void* q, const void* k, void* score
     // Round 4 measured the review's "every finalize workgroup re-merges all partials of its head" (256 per row at one stage per
     // workgroup): 8 stages per workgroup at B = 8 (32 partials per row) left finalize_kernel at 44.5 us - it is bound by its
     // ~790 vector instructions per wave, not by those reads - and the K scan at 344 us.  One stage stays.
-    const int64_t target = logits_v2_wgs() > 0 ? logits_v2_wgs() : (C > 8 ? (int64_t)4 * cus : total);
+    // Round 6: a launch of at most TWO rounds of the chip's 4-per-CU residency (S = 8192 at B = 1: 2048 stages) runs as ONE round of
+    // two-stage workgroups - 14.4 -> 13.5 us there (tools/probes/scan_stages_probe.py); one stage per workgroup stays the
+    // fastest from three rounds up (S = 16384: 25.2 either way, S = 32768: 45.9 against 48-51 us).
+    const int64_t target = logits_v2_wgs() > 0 ? logits_v2_wgs()
+                         : (C > 8 ? (int64_t)4 * cus : (total > (int64_t)4 * cus && total <= (int64_t)8 * cus ? (int64_t)4 * cus : total));
     int nst = (int)((total + target - 1) / target);
     nst = std::max(1, std::min(nst, std::min(sph, 64)));
     lp.nst = nst;
