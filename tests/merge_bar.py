@@ -9,7 +9,7 @@ ties it.  `tools/parity_fuzz.py` seed 60606 case 507 is such a case (one dropped
 
 `check_merge` therefore asserts: K and V equal the oracle's bit for bit - OR the kernel's own drop list equals the oracle's,
 every pivot that differs is reachable by moving dot products by at most one fp32 unit (each similarity may take the rounding of
-exact*(1 -/+ 2^-22); the kernel's pivot must be a possible FIRST maximum), such rows are at most max(2, 1e-4 x dropped rows), and the
+exact*(1 -/+ 2^-22); the kernel's pivot must be a possible FIRST maximum), such rows are at most max(2, 2e-3 x dropped rows), and the
 oracle's arithmetic run with the KERNEL's pivots reproduces the kernel's K and V bit for bit (everything behind the argmax is
 exact).  The kernel's drop list and pivots are read from the workspace of the call (layout of pkv_api.hip `merge_ws`); the
 reference's pivots are `oracle.merge_pivots` - the very ops of :150-151, not an fp32 replica: ATen's CPU matmul of fp16 tensors is
@@ -97,5 +97,8 @@ def check_merge(ops, ke, ve, idx, w, km, vm, what=""):
                 moved += 1
             k2, v2 = merge_with_pivots(ke[b, h], ve[b, h], sel, drop, pk, w)
             assert torch.equal(km[b, h], k2) and torch.equal(vm[b, h], v2), (what, "merge arithmetic behind the kernel's own pivots", b, h)
-    assert 0 < moved <= max(2, int(1e-4 * len(drop) * B * H)), (what, "pivots moved", moved, len(drop) * B * H)
+    # every differing pivot was verified one by one above; the count is a sanity limit, not the statement.  Inputs with exact
+    # duplicates among the keys ("planted": similarities tie structurally, fp16 similarities near 1 sit 5e-4 apart) reach 1e-3
+    # of the dropped rows (tools/parity_fuzz.py seed 141421 case 880: 9 of 8856, the same with the library of round 5)
+    assert 0 < moved <= max(2, int(2e-3 * len(drop) * B * H)), (what, "pivots moved", moved, len(drop) * B * H)
     return moved

@@ -12,7 +12,8 @@ seeds and false on some.  The bar used by the GPU tests:
   * such moved products are rare: at most max(2, 1e-4 x elements) per tensor (a heavy key's product counts once);
   * elements that differ at all: at most `frac_bar` of the tensor (the two sides evaluate exp / sums in different orders);
   * pooling adds nothing: the kernel's pooled scores are the oracle's pooling of the kernel's own un-pooled scores (max: exact,
-    avg: within 1 ulp), and every pooled element beyond 1 ulp lies within kernel/2 of an explained un-pooled one.
+    avg: within 1 ulp), and every pooled element beyond 1 ulp lies within kernel/2 of an explained un-pooled one (avg pooling:
+    or is 2 units off within kernel/2 of an un-pooled score that differs by its allowed unit - an average re-rounds).
 """
 import numpy as np
 import torch
@@ -100,6 +101,16 @@ def check_window_scores(q, kx, w, pool, ks, reduce, got_pooled, unpooled_fn, sca
     marked = np.zeros(d.shape, dtype=bool)
     for (b, h, j) in pos:
         marked[b, h, max(0, j - reach):j + reach + 1] = True
+    if pool == "avgpool":
+        # an average re-rounds: ONE tap that differs by a unit of ITS last place (allowed above) and dominates its window moves the
+        # average by up to ~1.6 units of the average's last place, i.e. 2 after rounding (tools/parity_fuzz.py seed 141421 case
+        # 140: avgpool 13, window 4, fp16, outlier inputs).  Two units, and only within reach of an un-pooled score that differs.
+        du = np.abs(ord16(got_u) - ord16(want_u)) > 0
+        near = np.zeros(d.shape, dtype=bool)
+        for sh in range(-reach, reach + 1):
+            src = du[..., max(0, -sh):du.shape[-1] - max(0, sh)]
+            near[..., max(0, sh):near.shape[-1] - max(0, -sh)] |= src
+        marked |= near & (d <= 2)
     assert not (d > 1)[~marked].any(), (what, "a pooled score beyond 1 ulp away from every explained un-pooled one")
     return rep
 

@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pyramidkv_amd as P
 from inputs import make_qkv, bits
 from merge_bar import check_merge
+from score_bar import check_window_scores
 from oracle import pkv_oracle as O
 DEV = "cuda"
 
@@ -36,10 +37,15 @@ t0, n, fails, kinds = time.time(), 0, [], {}
 fp = dict(score_checks=0, over_1ulp=0, over_half_percent=0, max_ulp=0, max_frac=0.0)
 
 
-def fp_check(got, want, what):
+def fp_stats(got, want):
     frac, mx = score_diff(got, want)
     fp["score_checks"] += 1; fp["over_1ulp"] += mx > 1; fp["over_half_percent"] += frac > 5e-3
     fp["max_ulp"] = max(fp["max_ulp"], mx); fp["max_frac"] = max(fp["max_frac"], frac)
+    return frac, mx
+
+
+def fp_check(got, want, what):
+    frac, mx = fp_stats(got, want)
     assert mx <= 8 and frac <= 2e-2, (what, frac, mx)
 while time.time() - t0 < budget:
     pol = str(rng.choice(["window", "window", "h2o", "adakv", "merge", "pyramid"]))
@@ -64,7 +70,10 @@ while time.time() - t0 < budget:
         if pol in ("window", "pyramid", "merge"):
             want = O.pool_scores(O.window_scores(q, ke, w), pool, ks)
             got = P.ops.score_window(qd, kd, w, pool, ks, kv_group=G).cpu()
-            fp_check(got, want, "scores")
+            fp_stats(got, want)
+            # the suite's bar (tests/score_bar.py): within a unit, or explained by one moved product; no bar on the FRACTION of
+            # scores that differ by their allowed unit - it has no principled bound (window 4, fp16, outlier inputs reach 5 %)
+            check_window_scores(q, ke, w, pool, ks, "sum", got, lambda: P.ops.score_window(qd, kd, w, None, 1, kv_group=G).cpu(), frac_bar=1.0, what="scores")
             kc, vc, idx = P.ops.compress(qd, kd, vd, w, kk, pool, ks, kv_group=G, return_indices=True)
             idx = idx.cpu().long()
             assert torch.equal(idx, O.topk_canonical(got, kk)), "indices"
